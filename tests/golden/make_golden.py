@@ -1,0 +1,246 @@
+"""Generate the golden fixtures in this directory from the reference itself.
+
+Runs ONLY in the build container (needs /root/reference and `transformers`);
+nothing here is imported by tests, the product or the GPU box - they read the
+.npz/.json files this script writes.
+
+How the reference is run: its two hot-path source files
+(laser/models/model_utils.py, laser/models/llava_clip_model_v3.py) are loaded
+from /root/reference with importlib, unmodified, after `sys.modules` is seeded
+with
+  * empty `laser` / `laser.models` packages (so laser/__init__.py, which pulls
+    in openai/spacy/torchvision, never runs),
+  * empty `jax` / `jax.numpy` modules (imported at module top, used only by the
+    *_jax helpers that this path never calls),
+  * a three-function `cv2` module (addWeighted / split / merge).  OpenCV is not
+    installed here, so `addWeighted` is restated from its published 8-bit
+    semantics (float32 weights, round to nearest even, saturate) - the one piece
+    of arithmetic in these fixtures that is not the third party's own code.
+`PredicateModel.__init__` (network downloads) is bypassed; the instance gets
+three seeded random-init HF `CLIPModel`s whose `get_*_features` return the
+pooled tensor as transformers 4.46.2 did, HF's PIL image processor with CLIP
+defaults, and the repo's deterministic HashTokenizer.  `forward()` itself runs
+unmodified.
+
+Usage:  python tests/golden/make_golden.py
+"""
+from __future__ import annotations
+
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from laser_amd.config import ClipConfig, TINY, VIT_B32  # noqa: E402
+from laser_amd.synthetic import make_clip_batch  # noqa: E402
+from laser_amd.tokenizer import HashTokenizer  # noqa: E402
+from laser_amd.weights import predicate_model_state_dict, split_predicate_state_dict  # noqa: E402
+sys.path.insert(0, HERE)
+from cases import FORWARD_CASES, build_case_batch  # noqa: E402
+
+
+# --------------------------------------------------------------------------
+# reference loading
+# --------------------------------------------------------------------------
+def _cv2_shim():
+    cv2 = types.ModuleType("cv2")
+
+    def addWeighted(src1, alpha, src2, beta, gamma):
+        t = src1.astype(np.float32) * np.float32(alpha) + src2.astype(np.float32) * np.float32(beta) + np.float32(gamma)
+        return np.clip(np.rint(t), 0, 255).astype(np.uint8)
+
+    cv2.addWeighted = addWeighted
+    cv2.split = lambda img: tuple(np.ascontiguousarray(img[:, :, c]) for c in range(img.shape[2]))
+    cv2.merge = lambda chans: np.stack(list(chans), axis=-1)
+    return cv2
+
+
+def load_reference():
+    for name in ("laser", "laser.models"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    jax = types.ModuleType("jax")
+    jnp = types.ModuleType("jax.numpy")
+    jax.numpy = jnp
+    sys.modules["jax"], sys.modules["jax.numpy"] = jax, jnp
+    sys.modules["cv2"] = _cv2_shim()
+    mods = {}
+    for name, rel in (("laser.models.model_utils", "laser/models/model_utils.py"),
+                      ("laser.models.llava_clip_model_v3", "laser/models/llava_clip_model_v3.py")):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        mods[name] = mod
+    return mods["laser.models.model_utils"], mods["laser.models.llava_clip_model_v3"]
+
+
+def hf_clip(cfg: ClipConfig, sd):
+    from transformers import CLIPConfig, CLIPModel
+
+    class PooledCLIP(CLIPModel):
+        def get_image_features(self, *a, **k):
+            return super().get_image_features(*a, **k).pooler_output
+
+        def get_text_features(self, *a, **k):
+            return super().get_text_features(*a, **k).pooler_output
+
+    hc = CLIPConfig(
+        text_config=dict(vocab_size=cfg.vocab, hidden_size=cfg.t_hidden, intermediate_size=cfg.t_ffn,
+                         num_hidden_layers=cfg.t_layers, num_attention_heads=cfg.t_heads,
+                         max_position_embeddings=cfg.max_pos, projection_dim=cfg.proj,
+                         eos_token_id=cfg.eos_token_id, bos_token_id=cfg.bos_token_id, pad_token_id=1,
+                         layer_norm_eps=cfg.ln_eps),
+        vision_config=dict(hidden_size=cfg.v_hidden, intermediate_size=cfg.v_ffn, num_hidden_layers=cfg.v_layers,
+                           num_attention_heads=cfg.v_heads, image_size=cfg.image, patch_size=cfg.patch,
+                           projection_dim=cfg.proj, layer_norm_eps=cfg.ln_eps),
+        projection_dim=cfg.proj, logit_scale_init_value=cfg.logit_scale_init)
+    m = PooledCLIP(hc)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("position_ids") for k in missing), missing
+    return m.eval()
+
+
+def build_reference_model(ref_model_mod, cfg: ClipConfig, seed: int, logit_scale: float):
+    from transformers.models.clip.image_processing_pil_clip import CLIPImageProcessorPil
+    towers = split_predicate_state_dict(predicate_model_state_dict(cfg, seed, logit_scale))
+    pm = ref_model_mod.PredicateModel.__new__(ref_model_mod.PredicateModel)
+    torch.nn.Module.__init__(pm)
+    pm.device = "cpu"
+    pm.clip_tokenizer = HashTokenizer(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    pm.clip_cate_model = hf_clip(cfg, towers["clip_cate_model"])
+    pm.clip_unary_model = hf_clip(cfg, towers["clip_unary_model"])
+    pm.clip_binary_model = hf_clip(cfg, towers["clip_binary_model"])
+    if cfg.image == 224:
+        pm.clip_processor = CLIPImageProcessorPil()
+    else:
+        pm.clip_processor = CLIPImageProcessorPil(size={"shortest_edge": cfg.image},
+                                                  crop_size={"height": cfg.image, "width": cfg.image})
+    return pm
+
+
+# --------------------------------------------------------------------------
+# serialisation of the reference's dict outputs
+# --------------------------------------------------------------------------
+def _enc_key(k):
+    if isinstance(k, tuple):
+        return [_enc_key(x) for x in k]
+    if isinstance(k, (np.integer,)):
+        return int(k)
+    return k
+
+
+def pack_outputs(out):
+    cate, unary, binary, dummy = out[:4]
+    rec = {
+        "cate_keys": {str(v): [_enc_key(k) for k in d] for v, d in cate.items()},
+        "unary_keys": {str(v): [_enc_key(k) for k in d] for v, d in unary.items()},
+        "binary_keys": [[_enc_key(k) for k in d] for d in binary],
+    }
+    arrays = {"dummy_prob": np.float32(float(dummy))}
+    for v, d in cate.items():
+        arrays[f"cate_vals_{v}"] = np.array([float(x) for x in d.values()], dtype=np.float32)
+    for v, d in unary.items():
+        arrays[f"unary_vals_{v}"] = np.array([float(x) for x in d.values()], dtype=np.float32)
+    for v, d in enumerate(binary):
+        arrays[f"binary_vals_{v}"] = np.array([float(x) for x in d.values()], dtype=np.float32)
+    if len(out) == 5:
+        emb = out[4]
+        rec["cate_object_ids"] = {str(v): [_enc_key(k) for k in ids] for v, ids in emb["cate_object_ids"].items()}
+        rec["binary_object_pairs"] = {str(v): [_enc_key(k) for k in ids] for v, ids in emb["binary_object_pairs"].items()}
+        for nm in ("cate_obj_clip_features", "unary_obj_clip_features", "binary_obj_pair_features"):
+            for v, t in emb[nm].items():
+                if isinstance(t, torch.Tensor):
+                    arrays[f"{nm}_{v}"] = t.detach().float().numpy()
+    return rec, arrays
+
+
+# --------------------------------------------------------------------------
+# cases
+# --------------------------------------------------------------------------
+def gen_function_goldens(mu):
+    """Goldens for model_utils functions + HF preprocessing, S = 64 and 224."""
+    from transformers.models.clip.image_processing_pil_clip import CLIPImageProcessorPil
+    rng = np.random.default_rng(1234)
+    H, W = 180, 260
+    b = make_clip_batch(77, n_videos=1, frames=1, objects=6, H=H, W=W, k_cate=1, k_unary=1, k_binary=1,
+                        min_box=10, max_box=170)
+    frame = b.batched_videos[0]
+    arrays = {"frame": frame}
+    meta = {"objects": [], "pairs": []}
+    proc64 = CLIPImageProcessorPil(size={"shortest_edge": 64}, crop_size={"height": 64, "width": 64})
+    proc224 = CLIPImageProcessorPil()
+    # mixed bbox formats, as crop_image_contain_bboxes accepts them
+    for i, (m, bb) in enumerate(zip(b.batched_masks, b.batched_bboxes)):
+        arrays[f"mask_{i}"] = np.packbits(m[..., 0], axis=None)
+        fmt = ["dict", "list", "tuple_float", "ndarray"][i % 4]
+        if fmt == "dict":
+            box = bb
+        elif fmt == "list":
+            box = [bb["x1"], bb["y1"], bb["x2"], bb["y2"]]
+        elif fmt == "tuple_float":
+            box = (bb["x2"] + 0.7, bb["y1"] + 0.2, bb["x1"] + 0.9, bb["y2"] + 0.5)   # swapped x, float -> int()
+        else:
+            box = np.array([bb["x1"], bb["y2"], bb["x2"], bb["y1"], 0.5])            # swapped y, extra field
+        obj_img = mu.extract_single_object(frame, m, 0.8)
+        crop = mu.crop_image_contain_bboxes(obj_img, [box], "golden")
+        arrays[f"obj_full_{i}"] = obj_img
+        px64 = proc64(images=[crop], return_tensors="np")["pixel_values"][0]
+        arrays[f"obj_px64_{i}"] = px64.astype(np.float32)
+        meta["objects"].append({"fmt": fmt, "box": [float(x) for x in (box.values() if isinstance(box, dict) else box)]
+                                if not isinstance(box, dict) else {k: int(v) for k, v in box.items()},
+                                "crop_shape": list(crop.shape)})
+        if i < 2:
+            arrays[f"obj_px224_{i}"] = proc224(images=[crop], return_tensors="np")["pixel_values"][0].astype(np.float32)
+    for (a, c) in [(0, 1), (1, 0), (2, 5), (4, 3), (3, 3)]:
+        img = mu.extract_object_subject(frame, b.batched_masks[a], b.batched_masks[c], alpha=0.5, white_alpha=0.8)
+        crop = mu.crop_image_contain_bboxes(img, [b.batched_bboxes[a], b.batched_bboxes[c]], "golden")
+        arrays[f"pair_full_{a}_{c}"] = img
+        arrays[f"pair_px64_{a}_{c}"] = proc64(images=[crop], return_tensors="np")["pixel_values"][0].astype(np.float32)
+        meta["pairs"].append({"from": a, "to": c, "crop_shape": list(crop.shape)})
+    # non-default blend strengths
+    img = mu.extract_object_subject(frame, b.batched_masks[0], b.batched_masks[2], alpha=0.3, white_alpha=0.65)
+    arrays["pair_full_alt"] = img
+    arrays["obj_full_alt"] = mu.extract_single_object(frame, b.batched_masks[1], 0.35)
+    # whole-frame pass through the processor (the dummy-pair path)
+    arrays["frame_px64"] = proc64(images=[frame], return_tensors="np")["pixel_values"][0].astype(np.float32)
+    meta["bboxes"] = [{k: int(v) for k, v in bb.items()} for bb in b.batched_bboxes]
+    meta["H"], meta["W"] = H, W
+    np.savez_compressed(os.path.join(HERE, "functions.npz"), **arrays)
+    json.dump(meta, open(os.path.join(HERE, "functions.json"), "w"), indent=1)
+    print("functions.npz", sum(a.nbytes for a in arrays.values()) // 1024, "KiB raw")
+
+
+def gen_forward_goldens(ref_model_mod):
+    from laser_amd.config import config_by_name
+    index = {}
+    for name, (cfg_name, wseed, bk, fk) in FORWARD_CASES.items():
+        cfg = config_by_name(cfg_name)
+        torch.manual_seed(0)
+        pm = build_reference_model(ref_model_mod, cfg, wseed, logit_scale=float(np.log(100.0)))
+        b = build_case_batch(name)
+        with torch.no_grad():
+            out = pm(**b.forward_kwargs(), **fk)
+        rec, arrays = pack_outputs(out)
+        rec.update({"cfg": cfg_name, "weight_seed": wseed, "batch": bk, "forward": fk, "logit_scale": float(np.log(100.0))})
+        np.savez_compressed(os.path.join(HERE, f"forward_{name}.npz"), **arrays)
+        index[name] = rec
+        print(name, {k: v.shape for k, v in arrays.items() if hasattr(v, "shape") and v.ndim}, float(out[3]))
+    json.dump(index, open(os.path.join(HERE, "forward_index.json"), "w"))
+
+
+if __name__ == "__main__":
+    mu, mm = load_reference()
+    gen_function_goldens(mu)
+    gen_forward_goldens(mm)

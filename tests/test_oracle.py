@@ -1,0 +1,122 @@
+"""CPU tests: the oracle (oracle/) against the golden fixtures produced by the
+reference's own code, and against Pillow where it is installed."""
+import numpy as np
+import pytest
+import torch
+
+from golden_io import compare_prob_dicts, load_forward_case, load_functions, object_box
+from cases import FORWARD_CASES, build_case_batch
+
+from laser_amd.config import config_by_name
+from laser_amd.tokenizer import HashTokenizer
+from laser_amd.weights import predicate_model_state_dict, split_predicate_state_dict
+from oracle import crop_ref, resample_ref
+from oracle.forward_ref import OraclePredicateModel
+
+
+def test_blend_known_answers():
+    luts = crop_ref.blend_luts(0.5, 0.8)
+    assert luts["white"][100] == 224 and luts["white"][0] == 204 and luts["white"][255] == 255
+    assert luts["tint"][100] == 177 and luts["tint"][254] == 254
+    assert (luts["keep"] == np.arange(256)).all()
+
+
+def test_crop_functions_match_reference():
+    meta, z, masks = load_functions()
+    frame = z["frame"]
+    for i, mo in enumerate(meta["objects"]):
+        full = crop_ref.extract_single_object(frame, masks[i], 0.8)
+        assert np.array_equal(full, z[f"obj_full_{i}"])
+        crop = crop_ref.crop_image_contain_bboxes(full, [object_box(mo)], "t")
+        assert list(crop.shape) == mo["crop_shape"]
+        px = resample_ref.preprocess(crop, 64)
+        assert np.array_equal(px, z[f"obj_px64_{i}"]), f"object {i} pixel_values differ"
+        if i < 2:
+            assert np.array_equal(resample_ref.preprocess(crop, 224), z[f"obj_px224_{i}"])
+    for mp in meta["pairs"]:
+        a, c = mp["from"], mp["to"]
+        full = crop_ref.extract_object_subject(frame, masks[a], masks[c], 0.5, 0.8)
+        assert np.array_equal(full, z[f"pair_full_{a}_{c}"])
+        crop = crop_ref.crop_image_contain_bboxes(full, [meta["bboxes"][a], meta["bboxes"][c]], "t")
+        assert list(crop.shape) == mp["crop_shape"]
+        assert np.array_equal(resample_ref.preprocess(crop, 64), z[f"pair_px64_{a}_{c}"])
+    assert np.array_equal(crop_ref.extract_object_subject(frame, masks[0], masks[2], 0.3, 0.65), z["pair_full_alt"])
+    assert np.array_equal(crop_ref.extract_single_object(frame, masks[1], 0.35), z["obj_full_alt"])
+    assert np.array_equal(resample_ref.preprocess(frame, 64), z["frame_px64"])
+
+
+def test_blend_luts_equal_whole_frame_blend():
+    meta, z, masks = load_functions()
+    frame = z["frame"]
+    for alpha, wa in ((0.5, 0.8), (0.3, 0.65)):
+        luts = crop_ref.blend_luts(alpha, wa)
+        m = masks[1][..., 0]
+        want = crop_ref.extract_single_object(frame, masks[1], wa)
+        got = np.where(m[..., None], luts["keep"][frame], luts["white"][frame])
+        assert np.array_equal(got, want)
+        r, b = masks[0][..., 0], masks[2][..., 0]
+        want = crop_ref.extract_object_subject(frame, masks[0], masks[2], alpha, wa)
+        got = frame.copy()
+        got[..., 2] = np.where(r, luts["tint"][frame[..., 2]], frame[..., 2])
+        got[..., 0] = np.where(b, luts["tint"][frame[..., 0]], frame[..., 0])
+        got = np.where((r | b)[..., None], got, luts["white"][frame])
+        assert np.array_equal(got, want)
+
+
+def test_resampler_matches_pillow():
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(3)
+    shapes = [(224, 224), (224, 500), (500, 224), (57, 300), (400, 33), (719, 1279), (5, 7), (2, 2)]
+    for k, (h, w) in enumerate(shapes):
+        S = (224, 64, 336)[k % 3]
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        nh, nw = resample_ref.resize_output_size(h, w, S)
+        ref = np.array(Image.fromarray(img).resize((nw, nh), resample=Image.BICUBIC))
+        top, left = (nh - S) // 2, (nw - S) // 2
+        assert np.array_equal(resample_ref.resize_center_crop_u8(img, S), ref[top:top + S, left:left + S]), (h, w, S)
+
+
+def _oracle_for(name):
+    cfg_name, wseed, _, fk = FORWARD_CASES[name]
+    cfg = config_by_name(cfg_name)
+    towers = split_predicate_state_dict(predicate_model_state_dict(cfg, wseed, float(np.log(100.0))))
+    tok = HashTokenizer(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    return OraclePredicateModel(cfg, towers, tok), fk
+
+
+@pytest.mark.parametrize("name", [n for n in FORWARD_CASES if n.startswith("tiny")])
+def test_oracle_forward_matches_reference(name):
+    rec, cate, unary, binary, dummy, z = load_forward_case(name)
+    model, fk = _oracle_for(name)
+    out = model(**build_case_batch(name).forward_kwargs(), **fk)
+    atol = 2e-4 if fk.get("output_logit") else 2e-5
+    assert set(out[0].keys()) == set(cate.keys())
+    for v in cate:
+        compare_prob_dicts(out[0][v], cate[v], atol)
+        compare_prob_dicts(out[1][v], unary[v], atol)
+    assert len(out[2]) == len(binary)
+    for g, w in zip(out[2], binary):
+        compare_prob_dicts(g, w, atol)
+    assert abs(float(out[3]) - dummy) <= 1e-4
+    if fk.get("output_embeddings"):
+        emb = out[4]
+        for nm in ("cate_obj_clip_features", "unary_obj_clip_features", "binary_obj_pair_features"):
+            for v in emb[nm]:
+                np.testing.assert_allclose(emb[nm][v].numpy(), z[f"{nm}_{v}"], atol=2e-5, rtol=1e-4)
+        assert [tuple(x) for x in rec["cate_object_ids"]["0"]] == list(emb["cate_object_ids"][0])
+        want_pairs = [(p[0], p[1], tuple(p[2])) for p in rec["binary_object_pairs"]["0"]]
+        assert want_pairs == list(emb["binary_object_pairs"][0])
+
+
+def test_oracle_forward_b32_matches_reference():
+    name = "b32_infer"
+    rec, cate, unary, binary, dummy, z = load_forward_case(name)
+    model, fk = _oracle_for(name)
+    torch.set_num_threads(8)
+    out = model(**build_case_batch(name).forward_kwargs(), **fk)
+    for v in cate:
+        compare_prob_dicts(out[0][v], cate[v], 5e-5)
+        compare_prob_dicts(out[1][v], unary[v], 5e-5)
+    for g, w in zip(out[2], binary):
+        compare_prob_dicts(g, w, 5e-5)
+    np.testing.assert_allclose(out[4]["binary_obj_pair_features"][0].numpy(), z["binary_obj_pair_features_0"], atol=5e-5, rtol=1e-4)
