@@ -1,0 +1,194 @@
+/*
+ * sgclip.h - C ABI of the MI355X (gfx950) SGCLIP scoring kernels.
+ *
+ * The reference (video-fm/LASER) has no FFI or operator registry for this
+ * path: its boundary is the Python call PredicateModel.forward()
+ * (laser/models/llava_clip_model_v3.py:86-107), below which every step is a
+ * third-party library call.  Each entry point here replaces one of those
+ * library calls; the citation says which.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SGCLIP_E* code on error;
+ *     sgclip_last_error() returns a thread-local message for the last error;
+ *   - pointers named *_dev are device pointers owned by the caller, everything
+ *     else is host memory; no function allocates or frees device memory, and
+ *     no function synchronises: work is enqueued on `stream` (a hipStream_t
+ *     passed as void*, NULL = the default stream);
+ *   - matrices are row-major; "bf16" is the upper half of an IEEE fp32.
+ */
+#ifndef SGCLIP_H
+#define SGCLIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGCLIP_OK 0
+#define SGCLIP_EINVAL (-1)   /* bad argument (shape, alignment, range)        */
+#define SGCLIP_ENOSPC (-2)   /* caller-provided workspace too small           */
+#define SGCLIP_ELAUNCH (-3)  /* HIP reported an error at launch               */
+#define SGCLIP_EBBOX (-4)    /* empty crop box: the reference's "image bbox issue" assert */
+
+int sgclip_abi_version(void);
+const char *sgclip_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * (1) mask-guided crop + resize + normalize.
+ *
+ * Replaces, per crop, the host chain
+ *   extract_single_object / extract_object_subject  (laser/models/model_utils.py:29-56, 119-140)
+ *   crop_image_contain_bboxes                        (laser/models/model_utils.py:87-117)
+ *   clip_processor(images=...)                       (laser/models/llava_clip_model_v3.py:244, 443)
+ * The box in each entry is the already resolved slice [y1:y2, x1:x2] of the
+ * frame (0 <= x1 < x2 <= frame_w, same for y).
+ * ---------------------------------------------------------------------- */
+#define SGCLIP_CROP_OBJECT 0 /* inside mask_a: keep; outside: blend to white            */
+#define SGCLIP_CROP_PAIR 1   /* mask_a tints channel 2, mask_b tints channel 0; outside both: white */
+#define SGCLIP_CROP_PLAIN 2  /* no blend (the reference's dummy whole-frame "pair")    */
+
+typedef struct sgclip_crop {
+    int64_t frame_off;  /* byte offset of the u8[H,W,3] frame inside frames_dev  */
+    int64_t mask_a_off; /* byte offset of the u8[H,W] mask inside masks_dev, -1 = none */
+    int64_t mask_b_off;
+    int32_t frame_w, frame_h;
+    int32_t x1, y1, x2, y2;
+    int32_t mode;
+    int32_t reserved;
+} sgclip_crop_t; /* 56 bytes */
+
+#define SGCLIP_LAYOUT_CHW 0     /* out[n][c][y][x], n-major, row length S                 */
+#define SGCLIP_LAYOUT_PATCHES 1 /* out[n*P + py*G + px][c*p*p + ky*p + kx], row length kpad */
+#define SGCLIP_DTYPE_F32 0
+#define SGCLIP_DTYPE_BF16 1
+
+/* luts: host u8[768] = white[256] | keep[256] | tint[256] (level tables of the
+ * three blends); norm_lut: host f32[768] = value of level v in channel c at
+ * [c*256+v] after rescale+normalize.  frames_dev / masks_dev must be readable
+ * up to the next multiple of 4 bytes past frames_bytes / masks_bytes.
+ * crops: host table; crops_dev: device buffer of n_crops entries that this
+ * call fills (H2D copy on `stream`) unless crops_dev_ready != 0.
+ * lut_dev: device scratch of SGCLIP_CROP_LUT_BYTES that this call fills.     */
+#define SGCLIP_CROP_LUT_BYTES (768 + 768 * 4)
+int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_bytes, const uint8_t *masks_dev,
+                           size_t masks_bytes, const sgclip_crop_t *crops, sgclip_crop_t *crops_dev,
+                           int crops_dev_ready, int n_crops, const uint8_t *luts, const float *norm_lut,
+                           void *lut_dev, int S, int layout, int patch, int kpad, int out_dtype,
+                           void *out_dev, void *stream);
+
+/* ------------------------------------------------------------------------
+ * (2) CLIP towers.
+ *
+ * Replace model.get_image_features / model.get_text_features
+ * (laser/models/llava_clip_model_v3.py:63-82; transformers
+ * models/clip/modeling_clip.py CLIPVisionModel.forward, CLIPTextModel.forward
+ * and the two projections).  Weights live in two caller-owned device blobs per
+ * tower (bf16 matrices, f32 vectors) whose layout this library defines:
+ * query it with sgclip_tower_layout().
+ * ---------------------------------------------------------------------- */
+typedef struct sgclip_tower_desc {
+    int32_t kind;    /* 0 = vision, 1 = text                                  */
+    int32_t hidden;  /* d                                                      */
+    int32_t ffn;     /* f                                                      */
+    int32_t layers;
+    int32_t heads;   /* head_dim must be 64                                    */
+    int32_t tokens;  /* vision: patches+1; text: max positions                 */
+    int32_t proj;    /* E                                                      */
+    int32_t patch;   /* vision only                                            */
+    int32_t image;   /* vision only                                            */
+    int32_t vocab;   /* text only                                              */
+    int32_t eos_id;  /* text only                                              */
+    float ln_eps;
+} sgclip_tower_desc_t;
+
+/* tensor ids for sgclip_tower_layout */
+enum {
+    SGCLIP_T_PATCH_W = 0, /* bf16 [d, kpad]  (vision; kpad = 3*p*p rounded up to 64, zero padded) */
+    SGCLIP_T_CLS = 1,     /* f32 [d]         (vision)                          */
+    SGCLIP_T_POS = 2,     /* f32 [tokens, d]                                   */
+    SGCLIP_T_PRE_LN_W = 3, SGCLIP_T_PRE_LN_B = 4, /* f32 [d] (vision)          */
+    SGCLIP_T_LN1_W = 5, SGCLIP_T_LN1_B = 6,       /* per layer f32 [d]         */
+    SGCLIP_T_QKV_W = 7,   /* per layer bf16 [3d, d] rows q | k | v             */
+    SGCLIP_T_QKV_B = 8,   /* per layer f32 [3d]                                */
+    SGCLIP_T_O_W = 9, SGCLIP_T_O_B = 10,
+    SGCLIP_T_LN2_W = 11, SGCLIP_T_LN2_B = 12,
+    SGCLIP_T_FC1_W = 13, SGCLIP_T_FC1_B = 14, SGCLIP_T_FC2_W = 15, SGCLIP_T_FC2_B = 16,
+    SGCLIP_T_POST_LN_W = 17, SGCLIP_T_POST_LN_B = 18, /* vision post_layernorm / text final_layer_norm */
+    SGCLIP_T_PROJ_W = 19, /* bf16 [E, d]                                       */
+    SGCLIP_T_TOK_EMB = 20, /* f32 [vocab, d] (text)                            */
+    SGCLIP_T_COUNT = 21
+};
+
+/* Element offset and element count of tensor `id` (layer index for per-layer
+ * tensors, else 0) inside the bf16 blob (*is_bf16 = 1) or the f32 blob.
+ * id = -1 returns the total element counts: *offset = bf16 elements, *count = f32 elements. */
+int sgclip_tower_layout(const sgclip_tower_desc_t *desc, int id, int layer, int64_t *offset, int64_t *count,
+                        int *is_bf16);
+int sgclip_patch_kpad(int patch);
+
+size_t sgclip_vit_workspace_bytes(const sgclip_tower_desc_t *desc, int n_images);
+/* patches_dev: bf16 [n_images * P, kpad] as written by sgclip_crop_preprocess
+ * with SGCLIP_LAYOUT_PATCHES; out_dev: f32 [n_images, E] un-normalised features. */
+int sgclip_vit_encode(const sgclip_tower_desc_t *desc, const void *w_bf16_dev, const float *w_f32_dev,
+                      const void *patches_dev, int n_images, void *workspace_dev, size_t workspace_bytes,
+                      float *out_dev, void *stream);
+
+size_t sgclip_text_workspace_bytes(const sgclip_tower_desc_t *desc, int n_texts, int seq_len);
+/* ids_dev / attn_mask_dev: int32 [n_texts, seq_len] (mask may be NULL = all ones);
+ * out_dev: f32 [n_texts, E]. */
+int sgclip_text_encode(const sgclip_tower_desc_t *desc, const void *w_bf16_dev, const float *w_f32_dev,
+                       const int32_t *ids_dev, const int32_t *attn_mask_dev, int n_texts, int seq_len,
+                       void *workspace_dev, size_t workspace_bytes, float *out_dev, void *stream);
+
+/* ------------------------------------------------------------------------
+ * (3) similarity + softmax / sigmoid.
+ *
+ * Replaces clip_sim (laser/models/llava_clip_model_v3.py:41-47), its inline twin
+ * for pairs (:451-455) and the .softmax(dim=0) / .sigmoid() that follow
+ * (:275, :327, :459-461): out[k][n] = f(exp_logit_scale * <text_k, img_n> /
+ * (|text_k| |img_n|)), f applied along k independently for every column n.
+ * ---------------------------------------------------------------------- */
+#define SGCLIP_SIM_LOGIT 0
+#define SGCLIP_SIM_SOFTMAX 1
+#define SGCLIP_SIM_SIGMOID 2
+size_t sgclip_similarity_workspace_bytes(int K, int N);
+int sgclip_similarity(const float *text_dev, const float *img_dev, int K, int N, int E, float exp_logit_scale,
+                      int mode, float *out_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------
+ * (4) per-object mean of category probabilities over frames.
+ *
+ * Replaces the Python accumulation + torch.mean of
+ * laser/models/llava_clip_model_v3.py:296-311: out[k][g] = mean of
+ * probs[k][n] over the columns n with seg_ids[n] == g, summed in column order.
+ * ---------------------------------------------------------------------- */
+int sgclip_segment_mean(const float *probs_dev, const int32_t *seg_ids_dev, int K, int N, int G, float *out_dev,
+                        void *stream);
+
+/* ------------------------------------------------------------------------
+ * Building blocks, exported for unit tests and profiling.
+ * ---------------------------------------------------------------------- */
+#define SGCLIP_EPI_BIAS_BF16 0      /* C_bf16 = A W^T + bias                   */
+#define SGCLIP_EPI_BIAS_GELU_BF16 1 /* C_bf16 = quick_gelu(A W^T + bias)       */
+#define SGCLIP_EPI_BIAS_RESID_F32 2 /* C_f32 += A W^T + bias (in place)        */
+#define SGCLIP_EPI_PATCH_F32 3      /* C_f32[(m/P)*T + 1 + m%P] = A W^T + aux[(1 + m%P)]  (aux = pos emb, P = aux_rows) */
+#define SGCLIP_EPI_F32 4            /* C_f32 = A W^T                           */
+/* A: bf16 [M, K] (lda), W: bf16 [N, K] (ldw), C: [.., N] (ldc); K % 64 == 0.  */
+int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, int ldw, void *C_dev, int ldc, int M, int N,
+                     int K, int epilogue, const float *bias_dev, const float *aux_dev, int aux_rows,
+                     void *stream);
+/* y[r] = LayerNorm(x[row(r)]) * w + b; row(r) = row_idx_dev ? row_idx_dev[r] : r;
+ * x f32 with row stride x_stride elements; y bf16 or f32, contiguous rows.   */
+int sgclip_layernorm(const float *x_dev, int64_t x_stride, const int32_t *row_idx_dev, int rows, int d,
+                     const float *w_dev, const float *b_dev, float eps, int out_dtype, void *y_dev,
+                     void *stream);
+/* qkv: bf16 [n_seq*T, 3d]; out: bf16 [n_seq*T, d]; softmax(q k^T / 8 + mask) v per head. */
+int sgclip_attention(const void *qkv_dev, void *out_dev, int n_seq, int T, int heads, int causal,
+                     const int32_t *key_mask_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGCLIP_H */

@@ -1,0 +1,256 @@
+"""Torch-facing wrappers over the C ABI (torch supplies device memory and the
+stream; all arithmetic happens in libsgclip_hip.so)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import ClipConfig
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------------------
+# level tables (host, 256 entries each)
+# ---------------------------------------------------------------------------
+def blend_luts(alpha: float = 0.5, white_alpha: float = 0.8) -> np.ndarray:
+    """u8[768] = white | keep | tint.
+
+    white[p]: pixel outside the mask(s), the 8-bit weighted sum
+              p*(1-white_alpha) + 255*white_alpha in float32, rounded to nearest even
+              (laser/models/model_utils.py:54 and :138);
+    keep[p]:  pixel inside the object mask, p*(1-white_alpha) + p*white_alpha (:51-54);
+    tint[p]:  tinted channel, trunc(p + (255-p)*alpha) (:129,:132)."""
+    p = np.arange(256, dtype=np.float32)
+    a, b = np.float32(1 - white_alpha), np.float32(white_alpha)
+    white = np.clip(np.rint(p * a + np.float32(255) * b), 0, 255).astype(np.uint8)
+    keep = np.clip(np.rint(p * a + p * b), 0, 255).astype(np.uint8)
+    lv = np.arange(256, dtype=np.uint8)
+    tint = np.clip(lv + (255 - lv) * alpha, 0, 255).astype(np.uint8)
+    return np.concatenate([white, keep, tint])
+
+
+def normalize_lut(mean=CLIP_MEAN, std=CLIP_STD) -> np.ndarray:
+    """f32[768]: level v of channel c -> ((v * (1/255)) - mean[c]) / std[c] with the
+    dtype sequence of the HF processor (float64 rescale -> float32 -> float32 normalise)."""
+    lv = np.arange(256, dtype=np.uint8)
+    x = (lv.astype(np.float64) * (1 / 255)).astype(np.float32)
+    m, s = np.array(mean, dtype=np.float32), np.array(std, dtype=np.float32)
+    return np.concatenate([(x - m[c]) / s[c] for c in range(3)]).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# crop kernel
+# ---------------------------------------------------------------------------
+def crop_preprocess(frames: torch.Tensor, masks: Optional[torch.Tensor], entries, S: int, *, layout=_lib.LAYOUT_CHW,
+                    patch: int = 0, out_dtype=_lib.DTYPE_F32, alpha: float = 0.5, white_alpha: float = 0.8,
+                    mean=CLIP_MEAN, std=CLIP_STD, out: Optional[torch.Tensor] = None,
+                    entries_dev: Optional[torch.Tensor] = None, entries_dev_ready: bool = False) -> torch.Tensor:
+    """frames / masks: flat u8 CUDA buffers (with >= 4 bytes of slack at the end, see
+    `pad_bytes`); entries: ctypes array of _lib.CropEntry.  Returns [N,3,S,S] (CHW) or
+    [N*P, kpad] (patch layout)."""
+    lib = _lib.load()
+    n = len(entries)
+    dev = frames.device
+    tdt = torch.bfloat16 if out_dtype == _lib.DTYPE_BF16 else torch.float32
+    kpad = lib.sgclip_patch_kpad(patch) if layout == _lib.LAYOUT_PATCHES else 0
+    if out is None:
+        if layout == _lib.LAYOUT_PATCHES:
+            P = (S // patch) ** 2
+            # pad columns are never written by the kernel and must stay zero
+            out = torch.zeros((n * P, kpad), dtype=tdt, device=dev)
+        else:
+            out = torch.empty((n, 3, S, S), dtype=tdt, device=dev)
+    if entries_dev is None:
+        entries_dev = torch.empty(max(n, 1) * C.sizeof(_lib.CropEntry), dtype=torch.uint8, device=dev)
+    lut_dev = torch.empty(_lib.CROP_LUT_BYTES, dtype=torch.uint8, device=dev)
+    luts = np.ascontiguousarray(blend_luts(alpha, white_alpha))
+    nlut = np.ascontiguousarray(normalize_lut(mean, std))
+    rc = lib.sgclip_crop_preprocess(
+        frames.data_ptr(), frames.numel() - PAD, _ptr(masks), (masks.numel() - PAD) if masks is not None else 0,
+        C.addressof(entries) if n else None, entries_dev.data_ptr(), 1 if entries_dev_ready else 0, n,
+        luts.ctypes.data, nlut.ctypes.data, lut_dev.data_ptr(), S, layout, patch, kpad, out_dtype, out.data_ptr(),
+        _stream())
+    _lib.check(rc)
+    # lut_dev / entries_dev are consumed asynchronously: keep them alive until the stream has run
+    out._sgclip_keepalive = (lut_dev, entries_dev)
+    return out
+
+
+PAD = 16  # slack bytes appended to frame / mask buffers (the kernel reads whole dwords)
+
+
+def pad_bytes(flat_u8: np.ndarray) -> np.ndarray:
+    return np.concatenate([flat_u8.reshape(-1), np.zeros(PAD, dtype=np.uint8)])
+
+
+# ---------------------------------------------------------------------------
+# towers
+# ---------------------------------------------------------------------------
+def tower_desc(cfg: ClipConfig, kind: str) -> _lib.TowerDesc:
+    if kind == "vision":
+        return _lib.TowerDesc(0, cfg.v_hidden, cfg.v_ffn, cfg.v_layers, cfg.v_heads, cfg.v_tokens, cfg.proj, cfg.patch,
+                              cfg.image, 0, 0, cfg.ln_eps)
+    return _lib.TowerDesc(1, cfg.t_hidden, cfg.t_ffn, cfg.t_layers, cfg.t_heads, cfg.max_pos, cfg.proj, 0, 0, cfg.vocab,
+                          cfg.eos_token_id, cfg.ln_eps)
+
+
+class Tower:
+    """One CLIP tower's weights packed into the library's two device blobs."""
+
+    def __init__(self, cfg: ClipConfig, kind: str, sd: Dict[str, torch.Tensor], device):
+        self.cfg, self.kind, self.device = cfg, kind, torch.device(device)
+        self.desc = tower_desc(cfg, kind)
+        lib = _lib.load()
+        nb, nf, isb = C.c_int64(), C.c_int64(), C.c_int()
+        _lib.check(lib.sgclip_tower_layout(C.byref(self.desc), -1, 0, C.byref(nb), C.byref(nf), C.byref(isb)))
+        wb = torch.zeros(nb.value, dtype=torch.bfloat16)
+        wf = torch.zeros(nf.value, dtype=torch.float32)
+
+        def put(tid, layer, t):
+            off, cnt = C.c_int64(), C.c_int64()
+            _lib.check(lib.sgclip_tower_layout(C.byref(self.desc), tid, layer, C.byref(off), C.byref(cnt), C.byref(isb)))
+            t = t.detach().to("cpu", torch.float32).reshape(-1)
+            if t.numel() != cnt.value:
+                raise ValueError(f"tensor {tid} layer {layer}: {t.numel()} elements, layout expects {cnt.value}")
+            (wb if isb.value else wf)[off.value: off.value + cnt.value] = t.to(torch.bfloat16) if isb.value else t
+
+        L = _lib
+        pre = "vision_model" if kind == "vision" else "text_model"
+        d = cfg.v_hidden if kind == "vision" else cfg.t_hidden
+        layers = cfg.v_layers if kind == "vision" else cfg.t_layers
+        if kind == "vision":
+            kpad = lib.sgclip_patch_kpad(cfg.patch)
+            pw = torch.zeros(d, kpad)
+            pw[:, : 3 * cfg.patch * cfg.patch] = sd["vision_model.embeddings.patch_embedding.weight"].float().reshape(d, -1)
+            put(L.T_PATCH_W, 0, pw)
+            put(L.T_CLS, 0, sd["vision_model.embeddings.class_embedding"])
+            put(L.T_POS, 0, sd["vision_model.embeddings.position_embedding.weight"])
+            put(L.T_PRE_LN_W, 0, sd["vision_model.pre_layrnorm.weight"])
+            put(L.T_PRE_LN_B, 0, sd["vision_model.pre_layrnorm.bias"])
+            put(L.T_POST_LN_W, 0, sd["vision_model.post_layernorm.weight"])
+            put(L.T_POST_LN_B, 0, sd["vision_model.post_layernorm.bias"])
+            put(L.T_PROJ_W, 0, sd["visual_projection.weight"])
+        else:
+            put(L.T_TOK_EMB, 0, sd["text_model.embeddings.token_embedding.weight"])
+            put(L.T_POS, 0, sd["text_model.embeddings.position_embedding.weight"])
+            put(L.T_POST_LN_W, 0, sd["text_model.final_layer_norm.weight"])
+            put(L.T_POST_LN_B, 0, sd["text_model.final_layer_norm.bias"])
+            put(L.T_PROJ_W, 0, sd["text_projection.weight"])
+        for i in range(layers):
+            b = f"{pre}.encoder.layers.{i}"
+            put(L.T_LN1_W, i, sd[f"{b}.layer_norm1.weight"])
+            put(L.T_LN1_B, i, sd[f"{b}.layer_norm1.bias"])
+            put(L.T_QKV_W, i, torch.cat([sd[f"{b}.self_attn.{n}_proj.weight"].float() for n in "qkv"], dim=0))
+            put(L.T_QKV_B, i, torch.cat([sd[f"{b}.self_attn.{n}_proj.bias"].float() for n in "qkv"], dim=0))
+            put(L.T_O_W, i, sd[f"{b}.self_attn.out_proj.weight"])
+            put(L.T_O_B, i, sd[f"{b}.self_attn.out_proj.bias"])
+            put(L.T_LN2_W, i, sd[f"{b}.layer_norm2.weight"])
+            put(L.T_LN2_B, i, sd[f"{b}.layer_norm2.bias"])
+            put(L.T_FC1_W, i, sd[f"{b}.mlp.fc1.weight"])
+            put(L.T_FC1_B, i, sd[f"{b}.mlp.fc1.bias"])
+            put(L.T_FC2_W, i, sd[f"{b}.mlp.fc2.weight"])
+            put(L.T_FC2_B, i, sd[f"{b}.mlp.fc2.bias"])
+        self.wb = wb.to(self.device)
+        self.wf = wf.to(self.device)
+        self._ws: Optional[torch.Tensor] = None
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def encode_images(self, patches: torch.Tensor, n_images: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        lib = _lib.load()
+        need = lib.sgclip_vit_workspace_bytes(C.byref(self.desc), n_images)
+        ws = self._workspace(max(need, 256))
+        if out is None:
+            out = torch.empty((n_images, self.cfg.proj), dtype=torch.float32, device=self.device)
+        _lib.check(lib.sgclip_vit_encode(C.byref(self.desc), self.wb.data_ptr(), self.wf.data_ptr(), patches.data_ptr(),
+                                         n_images, ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()))
+        return out
+
+    def encode_text(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
+        lib = _lib.load()
+        K, T = input_ids.shape
+        ids = input_ids.to(self.device, torch.int32).contiguous()
+        am = None if attention_mask is None else attention_mask.to(self.device, torch.int32).contiguous()
+        need = lib.sgclip_text_workspace_bytes(C.byref(self.desc), K, T)
+        ws = self._workspace(max(need, 256))
+        out = torch.empty((K, self.cfg.proj), dtype=torch.float32, device=self.device)
+        _lib.check(lib.sgclip_text_encode(C.byref(self.desc), self.wb.data_ptr(), self.wf.data_ptr(), ids.data_ptr(),
+                                          _ptr(am), K, T, ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()))
+        out._sgclip_keepalive = (ids, am)
+        return out
+
+
+# ---------------------------------------------------------------------------
+# similarity / softmax / segment mean
+# ---------------------------------------------------------------------------
+def similarity(text: torch.Tensor, img: torch.Tensor, exp_logit_scale: float, mode: int,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    K, E = text.shape
+    N = img.shape[0]
+    text, img = text.contiguous(), img.contiguous()
+    if out is None:
+        out = torch.empty((K, N), dtype=torch.float32, device=text.device)
+    ws = torch.empty(max(lib.sgclip_similarity_workspace_bytes(K, N), 256), dtype=torch.uint8, device=text.device)
+    _lib.check(lib.sgclip_similarity(text.data_ptr(), img.data_ptr(), K, N, E, float(exp_logit_scale), mode,
+                                     out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+    out._sgclip_keepalive = (ws, text, img)
+    return out
+
+
+def segment_mean(probs: torch.Tensor, seg_ids: torch.Tensor, G: int) -> torch.Tensor:
+    lib = _lib.load()
+    K, N = probs.shape
+    out = torch.empty((K, G), dtype=torch.float32, device=probs.device)
+    seg = seg_ids.to(probs.device, torch.int32).contiguous()
+    _lib.check(lib.sgclip_segment_mean(probs.data_ptr(), seg.data_ptr(), K, N, G, out.data_ptr(), _stream()))
+    out._sgclip_keepalive = (seg,)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# building blocks (tests / profiling)
+# ---------------------------------------------------------------------------
+def gemm_bf16(A: torch.Tensor, W: torch.Tensor, C_out: torch.Tensor, epilogue: int, bias=None, aux=None, aux_rows=0):
+    lib = _lib.load()
+    M, K = A.shape
+    N = W.shape[0]
+    _lib.check(lib.sgclip_gemm_bf16(A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), C_out.data_ptr(),
+                                    C_out.stride(0), M, N, K, epilogue, _ptr(bias), _ptr(aux), aux_rows, _stream()))
+    return C_out
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, out_dtype=_lib.DTYPE_BF16,
+              row_idx: Optional[torch.Tensor] = None, rows: Optional[int] = None, x_stride: Optional[int] = None):
+    lib = _lib.load()
+    d = x.shape[-1]
+    rows = rows if rows is not None else (row_idx.numel() if row_idx is not None else x.shape[0])
+    y = torch.empty((rows, d), dtype=torch.bfloat16 if out_dtype == _lib.DTYPE_BF16 else torch.float32, device=x.device)
+    _lib.check(lib.sgclip_layernorm(x.data_ptr(), x_stride if x_stride is not None else x.stride(0), _ptr(row_idx), rows, d,
+                                    w.data_ptr(), b.data_ptr(), eps, out_dtype, y.data_ptr(), _stream()))
+    return y
+
+
+def attention(qkv: torch.Tensor, n_seq: int, T: int, heads: int, causal: bool, key_mask: Optional[torch.Tensor] = None):
+    lib = _lib.load()
+    out = torch.empty((n_seq * T, heads * 64), dtype=torch.bfloat16, device=qkv.device)
+    _lib.check(lib.sgclip_attention(qkv.data_ptr(), out.data_ptr(), n_seq, T, heads, 1 if causal else 0, _ptr(key_mask),
+                                    _stream()))
+    return out

@@ -1,0 +1,269 @@
+"""GPU unit tests: every C-ABI building block against a plain fp32 reference of
+the same op (torch on the same device) or, for the byte-exact crop kernel,
+against the CPU oracle and the golden vectors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from laser_amd import _lib, ops  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _rand_bf16(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 192, 128), (1000, 768, 768), (333, 64, 256), (4096, 2304, 768),
+                                   (50, 3072, 768), (777, 768, 3072)])
+def test_gemm_bias(dev, M, N, K):
+    A = _rand_bf16((M, K), dev, 1.0, 1)
+    W = _rand_bf16((N, K), dev, K ** -0.5, 2)
+    bias = torch.randn(N, device=dev)
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16(A, W, out, _lib.EPI_BIAS_BF16, bias=bias)
+    ref = A.float() @ W.float().t() + bias
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
+
+
+def test_gemm_asymmetric_identity(dev):
+    """A = I catches a transposed or permuted fragment map."""
+    K = 128
+    A = torch.eye(K, dtype=torch.bfloat16, device=dev)
+    W = (torch.arange(256 * K, device=dev).reshape(256, K) % 251).to(torch.bfloat16)
+    out = torch.empty((K, 256), dtype=torch.float32, device=dev)
+    ops.gemm_bf16(A, W, out, _lib.EPI_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(out, W.float().t())
+
+
+def test_gemm_epilogues(dev):
+    M, N, K = 300, 256, 192
+    A = _rand_bf16((M, K), dev, 1.0, 3)
+    W = _rand_bf16((N, K), dev, K ** -0.5, 4)
+    bias = torch.randn(N, device=dev)
+    ref = A.float() @ W.float().t()
+    # quick-GELU
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16(A, W, out, _lib.EPI_BIAS_GELU_BF16, bias=bias)
+    z = ref + bias
+    assert (out.float() - z * torch.sigmoid(1.702 * z)).abs().max().item() < 3e-2
+    # residual, fp32 in place
+    x0 = torch.randn(M, N, device=dev)
+    x = x0.clone()
+    ops.gemm_bf16(A, W, x, _lib.EPI_BIAS_RESID_F32, bias=bias)
+    assert (x - (x0 + ref + bias)).abs().max().item() < 1e-3
+    # plain fp32
+    o = torch.empty((M, N), dtype=torch.float32, device=dev)
+    ops.gemm_bf16(A, W, o, _lib.EPI_F32)
+    assert (o - ref).abs().max().item() < 1e-3
+    # patch embedding remap: row m -> (m // P) * (P + 1) + 1 + m % P, plus pos[1 + m % P]
+    P, imgs = 4, 75
+    pos = torch.randn(P + 1, N, device=dev)
+    xo = torch.full((imgs * (P + 1), N), 7.0, device=dev)
+    ops.gemm_bf16(A, W, xo, _lib.EPI_PATCH_F32, aux=pos, aux_rows=P)
+    want = torch.full_like(xo, 7.0)
+    rows = torch.arange(M, device=dev)
+    want[(rows // P) * (P + 1) + 1 + rows % P] = ref + pos[1 + rows % P]
+    torch.cuda.synchronize()
+    assert (xo - want).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("d", [128, 512, 768, 1024])
+def test_layernorm(dev, d):
+    x = torch.randn(777, d, device=dev) * 3 + 1
+    w, b = torch.randn(d, device=dev), torch.randn(d, device=dev)
+    ref = torch.nn.functional.layer_norm(x, (d,), w, b, 1e-5)
+    y = ops.layernorm(x, w, b, 1e-5, _lib.DTYPE_F32)
+    assert (y - ref).abs().max().item() < 2e-5
+    yb = ops.layernorm(x, w, b, 1e-5, _lib.DTYPE_BF16)
+    assert (yb.float() - ref).abs().max().item() < 5e-2
+    idx = torch.tensor([5, 0, 776, 13], dtype=torch.int32, device=dev)
+    yi = ops.layernorm(x, w, b, 1e-5, _lib.DTYPE_F32, row_idx=idx)
+    assert (yi - ref[idx.long()]).abs().max().item() < 2e-5
+    # strided rows (class-token pooling): every 7th row
+    ys = ops.layernorm(x, w, b, 1e-5, _lib.DTYPE_F32, rows=111, x_stride=7 * d)
+    assert (ys - ref[::7]).abs().max().item() < 2e-5
+
+
+def _attn_ref(qkv, n_seq, T, heads, causal, key_mask):
+    d = heads * 64
+    q, k, v = (qkv.float().view(n_seq, T, 3, heads, 64)[:, :, i].transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2) * 0.125
+    ok = torch.ones(n_seq, 1, T, T, dtype=torch.bool, device=qkv.device)
+    if causal:
+        ok = ok & torch.ones(T, T, dtype=torch.bool, device=qkv.device).tril()
+    if key_mask is not None:
+        ok = ok & key_mask.bool()[:, None, None, :]
+    s = s.masked_fill(~ok, float("-inf"))
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(n_seq * T, d)
+
+
+@pytest.mark.parametrize("n_seq,T,heads,causal", [(3, 50, 12, False), (2, 75, 8, True), (1, 577, 4, False), (5, 17, 2, False),
+                                                  (2, 32, 2, True), (7, 64, 3, False)])
+def test_attention(dev, n_seq, T, heads, causal):
+    qkv = _rand_bf16((n_seq * T, 3 * heads * 64), dev, 1.0, 5)
+    key_mask = None
+    if causal:
+        lens = torch.tensor([max(2, T - 9 * i) for i in range(n_seq)])
+        key_mask = (torch.arange(T)[None, :] < lens[:, None]).to(torch.int32).to(dev)
+    out = ops.attention(qkv, n_seq, T, heads, causal, key_mask)
+    ref = _attn_ref(qkv, n_seq, T, heads, causal, key_mask)
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs().max().item()
+    assert err < 3e-2, err
+
+
+def test_attention_exact_integers(dev):
+    """Small-integer q/k/v with one-hot softmax rows: checks the fragment maps exactly."""
+    n_seq, T, heads = 2, 50, 2
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.zeros(n_seq * T, 3 * heads * 64)
+    v = torch.randint(-8, 9, (n_seq * T, heads * 64), generator=g).float()
+    qkv[:, 2 * heads * 64:] = v
+    # q_t . k_s = 800 * [s == perm(t)] so softmax is one-hot at perm(t)
+    perm = torch.randperm(T, generator=g)
+    for s in range(n_seq):
+        for hd in range(heads):
+            for t in range(T):
+                qkv[s * T + t, hd * 64 + (t % 64)] = 80.0
+                qkv[s * T + perm[t], heads * 64 + hd * 64 + (t % 64)] = 80.0
+    qkv = qkv.to(torch.bfloat16).to(dev)
+    out = ops.attention(qkv, n_seq, T, heads, False, None).float().cpu()
+    want = torch.stack([v[s * T + perm[t]] for s in range(n_seq) for t in range(T)])
+    assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("K,N,E,mode", [(7, 5, 64, _lib.SIM_SOFTMAX), (200, 513, 512, _lib.SIM_SOFTMAX),
+                                        (50, 1000, 512, _lib.SIM_SIGMOID), (35, 64, 768, _lib.SIM_LOGIT), (1, 3, 64, _lib.SIM_SOFTMAX)])
+def test_similarity(dev, K, N, E, mode):
+    text, img = torch.randn(K, E, device=dev) * 3, torch.randn(N, E, device=dev) * 0.2
+    out = ops.similarity(text, img, 100.0, mode)
+    t, i = text.double(), img.double()
+    logits = (t / t.norm(dim=-1, keepdim=True)) @ (i / i.norm(dim=-1, keepdim=True)).t() * 100.0
+    ref = {_lib.SIM_LOGIT: logits, _lib.SIM_SOFTMAX: logits.softmax(0), _lib.SIM_SIGMOID: logits.sigmoid()}[mode]
+    torch.cuda.synchronize()
+    tol = 2e-3 if mode == _lib.SIM_LOGIT else 2e-4
+    assert (out.double() - ref).abs().max().item() < tol
+
+
+def test_segment_mean(dev):
+    K, N, G = 9, 100, 7
+    p = torch.rand(K, N, device=dev)
+    seg = torch.randint(0, G - 1, (N,), device=dev, dtype=torch.int32)  # group G-1 stays empty
+    out = ops.segment_mean(p, seg, G)
+    for g in range(G):
+        sel = seg == g
+        want = p[:, sel].mean(dim=1) if sel.any() else torch.zeros(K, device=dev)
+        assert (out[:, g] - want).abs().max().item() < 1e-6
+
+
+# ---------------------------------------------------------------------------
+# crop kernel: bit-exact against the oracle and the golden vectors
+# ---------------------------------------------------------------------------
+def _entries(rows):
+    arr = (_lib.CropEntry * len(rows))()
+    for e, r in zip(arr, rows):
+        (e.frame_off, e.mask_a_off, e.mask_b_off, e.frame_w, e.frame_h, e.x1, e.y1, e.x2, e.y2, e.mode) = r
+    return arr
+
+
+def test_crop_matches_golden_and_oracle(dev):
+    from golden_io import load_functions, object_box
+    from oracle import crop_ref, resample_ref
+    meta, z, masks = load_functions()
+    frame = z["frame"]
+    H, W = meta["H"], meta["W"]
+    frames_t = torch.from_numpy(ops.pad_bytes(frame)).to(dev)
+    masks_np = np.stack([m[..., 0].astype(np.uint8) for m in masks])
+    masks_t = torch.from_numpy(ops.pad_bytes(masks_np)).to(dev)
+    rows, want64 = [], []
+    for i, mo in enumerate(meta["objects"]):
+        x1, y1, x2, y2 = crop_ref.union_box([object_box(mo)])
+        rows.append((0, i * H * W, -1, W, H, x1, y1, x2, y2, _lib.CROP_OBJECT))
+        want64.append(z[f"obj_px64_{i}"])
+    for mp in meta["pairs"]:
+        a, c = mp["from"], mp["to"]
+        x1, y1, x2, y2 = crop_ref.union_box([meta["bboxes"][a], meta["bboxes"][c]])
+        rows.append((0, a * H * W, c * H * W, W, H, x1, y1, x2, y2, _lib.CROP_PAIR))
+        want64.append(z[f"pair_px64_{a}_{c}"])
+    rows.append((0, -1, -1, W, H, 0, 0, W, H, _lib.CROP_PLAIN))
+    want64.append(z["frame_px64"])
+    ent = _entries(rows)
+    out = ops.crop_preprocess(frames_t, masks_t, ent, 64).cpu().numpy()
+    for i, w in enumerate(want64):
+        assert np.array_equal(out[i], w), f"crop {i}: {np.abs(out[i] - w).max()} max diff, {(out[i] != w).sum()} px"
+    # S = 224 against the golden vectors and the oracle (down- and up-scaling)
+    ent224 = _entries(rows[:4])
+    out224 = ops.crop_preprocess(frames_t, masks_t, ent224, 224).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(out224[i], z[f"obj_px224_{i}"])
+    for i in (2, 3):
+        full = crop_ref.extract_single_object(frame, masks[i], 0.8)
+        _, _, _, _, _, x1, y1, x2, y2, _ = rows[i]
+        assert np.array_equal(out224[i], resample_ref.preprocess(full[y1:y2, x1:x2], 224))
+    # patch (im2col) layout in bf16 equals the CHW result regrouped
+    p = 16
+    outp = ops.crop_preprocess(frames_t, masks_t, ent, 64, layout=_lib.LAYOUT_PATCHES, patch=p, out_dtype=_lib.DTYPE_BF16)
+    G = 64 // p
+    chw = torch.from_numpy(out).to(torch.bfloat16).float()
+    want = chw.view(len(rows), 3, G, p, G, p).permute(0, 2, 4, 1, 3, 5).reshape(len(rows) * G * G, 3 * p * p)
+    assert torch.equal(outp.float().cpu(), want)
+
+
+def test_crop_random_boxes_vs_oracle(dev):
+    """Seeded random frames / boxes incl. heavy down-scaling, odd alignments, 1-2 px wide crops; S = 64 and 336."""
+    from oracle import crop_ref, resample_ref
+    rng = np.random.default_rng(5)
+    H, W = 333, 517
+    frames = rng.integers(0, 256, size=(2, H, W, 3), dtype=np.uint8)
+    masks = rng.random((3, H, W)) < 0.5
+    frames_t = torch.from_numpy(ops.pad_bytes(frames)).to(dev)
+    masks_t = torch.from_numpy(ops.pad_bytes(masks.astype(np.uint8))).to(dev)
+    boxes = [(0, 0, W, H), (1, 2, 3, H), (5, 7, 505, 9), (100, 50, 101, 51), (13, 17, 517, 333), (250, 100, 314, 164),
+             (3, 3, 227, 227), (7, 300, 500, 333)]
+    for _ in range(12):
+        x1, y1 = int(rng.integers(0, W - 2)), int(rng.integers(0, H - 2))
+        boxes.append((x1, y1, int(rng.integers(x1 + 1, W + 1)), int(rng.integers(y1 + 1, H + 1))))
+    rows = []
+    for i, (x1, y1, x2, y2) in enumerate(boxes):
+        f, a, b = i % 2, i % 3, (i + 1) % 3
+        mode = (_lib.CROP_OBJECT, _lib.CROP_PAIR, _lib.CROP_PLAIN)[i % 3]
+        rows.append((f * H * W * 3, a * H * W, b * H * W, W, H, x1, y1, x2, y2, mode))
+    ent = _entries(rows)
+    for S, alpha, wa in ((64, 0.5, 0.8), (336, 0.3, 0.65)):
+        out = ops.crop_preprocess(frames_t, masks_t, ent, S, alpha=alpha, white_alpha=wa).cpu().numpy()
+        for i, r in enumerate(rows):
+            foff, aoff, boff, _, _, x1, y1, x2, y2, mode = r
+            fr = frames[foff // (H * W * 3)]
+            ma, mb = masks[aoff // (H * W)][..., None], masks[boff // (H * W)][..., None]
+            if mode == _lib.CROP_OBJECT:
+                full = crop_ref.extract_single_object(fr, ma, wa)
+            elif mode == _lib.CROP_PAIR:
+                full = crop_ref.extract_object_subject(fr, ma, mb, alpha, wa)
+            else:
+                full = fr
+            want = resample_ref.preprocess(full[y1:y2, x1:x2], S)
+            assert np.array_equal(out[i], want), f"S={S} crop {i} box {boxes[i]}: {(out[i] != want).sum()} values differ"
+
+
+def test_crop_errors(dev):
+    frames_t = torch.zeros(100 * 100 * 3 + ops.PAD, dtype=torch.uint8, device=dev)
+    with pytest.raises(AssertionError, match="image bbox issue"):
+        ops.crop_preprocess(frames_t, None, _entries([(0, -1, -1, 100, 100, 10, 10, 10, 20, _lib.CROP_PLAIN)]), 64)
+    with pytest.raises(_lib.SgclipError):
+        ops.crop_preprocess(frames_t, None, _entries([(0, -1, -1, 100, 100, 10, 10, 120, 20, _lib.CROP_PLAIN)]), 64)
+    with pytest.raises(_lib.SgclipError):
+        ops.crop_preprocess(frames_t, None, _entries([(0, -1, -1, 100, 100, 10, 10, 50, 20, _lib.CROP_OBJECT)]), 64)
