@@ -116,7 +116,7 @@ enum {
     SGCLIP_T_LN2_W = 11, SGCLIP_T_LN2_B = 12,
     SGCLIP_T_FC1_W = 13, SGCLIP_T_FC1_B = 14, SGCLIP_T_FC2_W = 15, SGCLIP_T_FC2_B = 16,
     SGCLIP_T_POST_LN_W = 17, SGCLIP_T_POST_LN_B = 18, /* vision post_layernorm / text final_layer_norm */
-    SGCLIP_T_PROJ_W = 19, /* bf16 [E, d]                                       */
+    SGCLIP_T_PROJ_W = 19, /* f32 [E, d]  (the projection runs at fp32-grade precision) */
     SGCLIP_T_TOK_EMB = 20, /* f32 [vocab, d] (text)                            */
     SGCLIP_T_COUNT = 21
 };
@@ -179,6 +179,10 @@ int sgclip_segment_mean(const float *probs_dev, const int32_t *seg_ids_dev, int 
 int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, int ldw, void *C_dev, int ldc, int M, int N,
                      int K, int epilogue, const float *bias_dev, const float *aux_dev, int aux_rows,
                      void *stream);
+/* y[rows, out] = x[rows, in] * w[out, in]^T for fp32 operands, each split into bf16
+ * hi + lo halves on the MFMA (three products), error ~2^-16 relative; in % 16 == 0. */
+int sgclip_linear_f32(const float *x_dev, const float *w_dev, int rows, int out_features, int in_features,
+                      float *y_dev, void *stream);
 /* y[r] = LayerNorm(x[row(r)]) * w + b; row(r) = row_idx_dev ? row_idx_dev[r] : r;
  * x f32 with row stride x_stride elements; y bf16 or f32, contiguous rows.   */
 int sgclip_layernorm(const float *x_dev, int64_t x_stride, const int32_t *row_idx_dev, int rows, int d,

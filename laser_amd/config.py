@@ -66,11 +66,12 @@ VIT_L14_336 = ClipConfig(
 )
 
 # Small geometry for fast parity tests (head_dim stays 64, the only head size
-# the attention kernel is built for).
+# the attention kernel is built for; the joint space keeps the 512 dimensions of
+# ViT-B/32 because the logit error of a given feature error scales with 1/sqrt(E)).
 TINY = ClipConfig(
     v_hidden=128, v_ffn=256, v_layers=2, v_heads=2, patch=16, image=64,
     t_hidden=128, t_ffn=256, t_layers=2, t_heads=2, vocab=1024, max_pos=77,
-    eos_token_id=1023, bos_token_id=1022, proj=64,
+    eos_token_id=1023, bos_token_id=1022, proj=512,
 )
 
 

@@ -84,32 +84,35 @@ __device__ __forceinline__ void split_bf16(const float *p, bf16x8 &hi, bf16x8 &l
     }
 }
 
-// one wave per 32 (keywords) x 32 (crops) tile; A = text rows, B = image rows
-__global__ __launch_bounds__(64) void sim_kernel(const float *__restrict__ text, const float *__restrict__ img,
-                                                 const float *__restrict__ inv_t, const float *__restrict__ inv_i, int K,
-                                                 int N, int E, float scale, float *__restrict__ out) {
+// out[a][b] = scale * sa[a] * sb[b] * <A_a, B_b> for fp32 rows A [Ma, E], B [Nb, E]:
+// one wave per 32 x 32 tile, every fp32 operand split into bf16 hi + lo and the
+// product taken as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (error ~2^-16
+// relative, i.e. fp32-grade for cosine logits).  sa / sb may be null (= 1).
+__global__ __launch_bounds__(64) void nt_split_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                      const float *__restrict__ sa, const float *__restrict__ sb, int Ma,
+                                                      int Nb, int E, float scale, float *__restrict__ out, int ldo) {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-    const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    const float *tr = text + (size_t)min(k0 + r, K - 1) * E + 8 * h;
-    const float *ir = img + (size_t)min(n0 + r, N - 1) * E + 8 * h;
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    const float *ar = A + (size_t)min(a0 + r, Ma - 1) * E + 8 * h;
+    const float *br = B + (size_t)min(b0 + r, Nb - 1) * E + 8 * h;
     f32x16 acc;
 #pragma unroll
     for (int g = 0; g < 16; g++) acc[g] = 0.f;
     for (int e = 0; e < E; e += 16) {
         bf16x8 ah, al, bh, bl;
-        split_bf16(tr + e, ah, al);
-        split_bf16(ir + e, bh, bl);
+        split_bf16(ar + e, ah, al);
+        split_bf16(br + e, bh, bl);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
     }
-    const int n = n0 + r;
-    if (n >= N) return;
-    const float sn = inv_i[n] * scale;
+    const int b = b0 + r;
+    if (b >= Nb) return;
+    const float sn = (sb ? sb[b] : 1.0f) * scale;
 #pragma unroll
     for (int g = 0; g < 16; g++) {
-        const int k = k0 + (g & 3) + 8 * (g >> 2) + 4 * h;
-        if (k < K) out[(size_t)k * N + n] = acc[g] * inv_t[k] * sn;
+        const int a = a0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (a < Ma) out[(size_t)a * ldo + b] = acc[g] * (sa ? sa[a] : 1.0f) * sn;
     }
 }
 
@@ -205,8 +208,8 @@ extern "C" int sgclip_similarity(const float *text_dev, const float *img_dev, in
     float *inv_t = (float *)workspace_dev, *inv_i = inv_t + K;
     hipLaunchKernelGGL(inv_norm_kernel, dim3(ceil_div(K, 4)), dim3(256), 0, stream, text_dev, K, E, inv_t);
     hipLaunchKernelGGL(inv_norm_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, stream, img_dev, N, E, inv_i);
-    hipLaunchKernelGGL(sim_kernel, dim3(ceil_div(N, 32), ceil_div(K, 32)), dim3(64), 0, stream, text_dev, img_dev, inv_t,
-                       inv_i, K, N, E, exp_logit_scale, out_dev);
+    hipLaunchKernelGGL(nt_split_kernel, dim3(ceil_div(N, 32), ceil_div(K, 32)), dim3(64), 0, stream, text_dev, img_dev,
+                       inv_t, inv_i, K, N, E, exp_logit_scale, out_dev, N);
     if (mode == SGCLIP_SIM_SOFTMAX) {
         hipLaunchKernelGGL(softmax_rows_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, stream, out_dev, K, N);
     } else if (mode == SGCLIP_SIM_SIGMOID) {
@@ -217,6 +220,21 @@ extern "C" int sgclip_similarity(const float *text_dev, const float *img_dev, in
         return SGCLIP_EINVAL;
     }
     return launch_check("sgclip_similarity");
+}
+
+extern "C" int sgclip_linear_f32(const float *x_dev, const float *w_dev, int rows, int out_features, int in_features,
+                                 float *y_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (rows == 0) return SGCLIP_OK;
+    if (!x_dev || !w_dev || !y_dev || rows < 0 || out_features <= 0 || in_features <= 0 || in_features % 16 != 0) {
+        set_error("sgclip_linear_f32: bad arguments rows=%d out=%d in=%d (in must be a multiple of 16)", rows,
+                  out_features, in_features);
+        return SGCLIP_EINVAL;
+    }
+    hipLaunchKernelGGL(nt_split_kernel, dim3(ceil_div(out_features, 32), ceil_div(rows, 32)), dim3(64), 0, stream, x_dev,
+                       w_dev, (const float *)nullptr, (const float *)nullptr, rows, out_features, in_features, 1.0f, y_dev,
+                       out_features);
+    return launch_check("sgclip_linear_f32");
 }
 
 extern "C" int sgclip_segment_mean(const float *probs_dev, const int32_t *seg_ids_dev, int K, int N, int G,

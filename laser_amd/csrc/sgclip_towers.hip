@@ -143,7 +143,7 @@ static bool build_layout(const sgclip_tower_desc_t *t, Layout &L) {
     of = lf0 + L.layer_stride_f32 * t->layers;
     addf(SGCLIP_T_POST_LN_W, d);
     addf(SGCLIP_T_POST_LN_B, d);
-    addb(SGCLIP_T_PROJ_W, E * d);
+    addf(SGCLIP_T_PROJ_W, E * d);
     L.total_bf = ob;
     L.total_f32 = of;
     return true;
@@ -161,7 +161,7 @@ struct Work {
     float *x;       // [rows, d] residual stream
     bf16_t *h;      // [rows, d] LN output / attention output
     bf16_t *big;    // [rows, max(3d, f)] qkv / mlp hidden
-    bf16_t *pooled; // [seqs, d]
+    float *pooled;  // [seqs, d] final LayerNorm output, fp32
     int32_t *rows;  // [seqs] pooled row index (text)
     size_t total;
 };
@@ -175,7 +175,7 @@ static Work carve(const sgclip_tower_desc_t *t, void *base, int64_t seqs, int64_
     w.x = (float *)(b + take((size_t)rows * d * 4));
     w.h = (bf16_t *)(b + take((size_t)rows * d * 2));
     w.big = (bf16_t *)(b + take((size_t)rows * wide * 2));
-    w.pooled = (bf16_t *)(b + take((size_t)seqs * d * 2));
+    w.pooled = (float *)(b + take((size_t)seqs * d * 4));
     w.rows = (int32_t *)(b + take((size_t)seqs * 4));
     w.total = o;
     return w;
@@ -286,9 +286,8 @@ extern "C" int sgclip_vit_encode(const sgclip_tower_desc_t *desc, const void *w_
                                SGCLIP_DTYPE_F32, w.x, stream));
         CHECK(run_layers(desc, Pp, w, nc, T, 0, nullptr, stream));
         CHECK(sgclip_layernorm(w.x, (int64_t)T * d, nullptr, nc, d, Pp.F(SGCLIP_T_POST_LN_W), Pp.F(SGCLIP_T_POST_LN_B),
-                               desc->ln_eps, SGCLIP_DTYPE_BF16, w.pooled, stream));
-        CHECK(sgclip_gemm_bf16(w.pooled, d, Pp.B(SGCLIP_T_PROJ_W), d, out_dev + (size_t)i0 * E, E, nc, E, d, SGCLIP_EPI_F32,
-                               nullptr, nullptr, 0, stream));
+                               desc->ln_eps, SGCLIP_DTYPE_F32, w.pooled, stream));
+        CHECK(sgclip_linear_f32(w.pooled, Pp.F(SGCLIP_T_PROJ_W), nc, E, d, out_dev + (size_t)i0 * E, stream));
     }
     return SGCLIP_OK;
 }
@@ -330,8 +329,7 @@ extern "C" int sgclip_text_encode(const sgclip_tower_desc_t *desc, const void *w
     CHECK(launch_check("text_embed_kernel"));
     CHECK(run_layers(desc, Pp, w, n_texts, T, 1, attn_mask_dev, stream));
     CHECK(sgclip_layernorm(w.x, d, w.rows, n_texts, d, Pp.F(SGCLIP_T_POST_LN_W), Pp.F(SGCLIP_T_POST_LN_B), desc->ln_eps,
-                           SGCLIP_DTYPE_BF16, w.pooled, stream));
-    CHECK(sgclip_gemm_bf16(w.pooled, d, Pp.B(SGCLIP_T_PROJ_W), d, out_dev, E, n_texts, E, d, SGCLIP_EPI_F32, nullptr,
-                           nullptr, 0, stream));
+                           SGCLIP_DTYPE_F32, w.pooled, stream));
+    CHECK(sgclip_linear_f32(w.pooled, Pp.F(SGCLIP_T_PROJ_W), n_texts, E, d, out_dev, stream));
     return SGCLIP_OK;
 }

@@ -81,13 +81,21 @@ def crop_preprocess(frames: torch.Tensor, masks: Optional[torch.Tensor], entries
     nlut = np.ascontiguousarray(normalize_lut(mean, std))
     rc = lib.sgclip_crop_preprocess(
         frames.data_ptr(), frames.numel() - PAD, _ptr(masks), (masks.numel() - PAD) if masks is not None else 0,
-        C.addressof(entries) if n else None, entries_dev.data_ptr(), 1 if entries_dev_ready else 0, n,
+        _host_table_ptr(entries) if n else None, entries_dev.data_ptr(), 1 if entries_dev_ready else 0, n,
         luts.ctypes.data, nlut.ctypes.data, lut_dev.data_ptr(), S, layout, patch, kpad, out_dtype, out.data_ptr(),
         _stream())
     _lib.check(rc)
     # lut_dev / entries_dev are consumed asynchronously: keep them alive until the stream has run
     out._sgclip_keepalive = (lut_dev, entries_dev)
     return out
+
+
+def _host_table_ptr(entries) -> int:
+    if isinstance(entries, np.ndarray):
+        if entries.dtype.itemsize != C.sizeof(_lib.CropEntry) or not entries.flags["C_CONTIGUOUS"]:
+            raise ValueError("crop table must be a C-contiguous array of 56-byte records")
+        return entries.ctypes.data
+    return C.addressof(entries)
 
 
 PAD = 16  # slack bytes appended to frame / mask buffers (the kernel reads whole dwords)

@@ -1,0 +1,377 @@
+"""SGCLIP scoring module for MI355X: same constructor arguments, `forward()`
+signature, return layout, asserts and exception classes as the reference's
+`PredicateModel` (reference: laser/models/llava_clip_model_v3.py:9-487).
+
+What runs where
+  host (Python, integer work):  box resolution, crop / pair index tables, pair
+      selection, key tables of the returned mappings        (:188-217, :342-392)
+  device (libsgclip_hip.so):     mask blend + crop + resize + normalize, the
+      three CLIP image towers, the text towers, similarity, softmax / sigmoid,
+      per-object category means                              (:137-186, :233-339, :397-474)
+There is no CPU fallback: without the HIP library or a GPU, construction fails.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, ops
+from .config import ClipConfig, config_by_name
+from .prob_dict import ProbDict
+from .weights import TOWER_PREFIXES, random_state_dict
+
+CROP_DTYPE = np.dtype([("frame_off", "<i8"), ("mask_a_off", "<i8"), ("mask_b_off", "<i8"), ("frame_w", "<i4"),
+                       ("frame_h", "<i4"), ("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4"), ("mode", "<i4"),
+                       ("reserved", "<i4")])
+assert CROP_DTYPE.itemsize == 56
+
+
+class _ParamTree(nn.Module):
+    """Nested parameter containers that reproduce HF's dotted state-dict names."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device):
+        super().__init__()
+        for name, t in sd.items():
+            node = self
+            parts = name.split(".")
+            for p in parts[:-1]:
+                if p not in node._modules:
+                    node.add_module(p, _ParamTree({}, device))
+                node = node._modules[p]
+            node.register_parameter(parts[-1], nn.Parameter(t.to(device), requires_grad=False))
+
+
+def resolve_union_box(bbox_ls: Sequence, data_id=None):
+    """Union box of `bbox_ls` exactly as the reference computes it
+    (laser/models/model_utils.py:93-115), including its two asserts."""
+    xs1, ys1, xs2, ys2 = [], [], [], []
+    for bbox in bbox_ls:
+        if isinstance(bbox, dict):
+            bx1, by1, bx2, by2 = bbox["x1"], bbox["y1"], bbox["x2"], bbox["y2"]
+        elif isinstance(bbox, (list, tuple, np.ndarray)):
+            bx1, by1, bx2, by2 = map(int, bbox[:4])
+        else:
+            raise ValueError(f"Unsupported bbox format: {type(bbox)}")
+        bx1, bx2 = min(bx1, bx2), max(bx1, bx2)
+        by1, by2 = min(by1, by2), max(by1, by2)
+        xs1.append(bx1); xs2.append(bx2); ys1.append(by1); ys2.append(by2)
+    x1, x2, y1, y2 = min(xs1), max(xs2), min(ys1), max(ys2)
+    assert x1 < x2, f"image bbox issue: {data_id}"
+    assert y1 < y2, f"image bbox issue: {data_id}"
+    return int(x1), int(y1), int(x2), int(y2)
+
+
+def slice_box(x1, y1, x2, y2, W, H, data_id=None):
+    """The pixels `img[y1:y2, x1:x2]` selects (model_utils.py:117): Python slice
+    clamping / negative wrap-around included."""
+    xa, xb, _ = slice(x1, x2).indices(W)
+    ya, yb, _ = slice(y1, y2).indices(H)
+    if xb <= xa or yb <= ya:
+        raise ValueError(f"crop box [{y1}:{y2}, {x1}:{x2}] selects no pixel of a {H}x{W} frame: {data_id}")
+    return xa, ya, xb, yb
+
+
+class DeviceInputs:
+    """Frames and masks of one forward() call resident in HBM."""
+
+    def __init__(self, frames: torch.Tensor, frame_off: List[int], frame_hw: List[tuple], masks: Optional[torch.Tensor],
+                 mask_off: List[int], mask_ndim: List[int]):
+        self.frames, self.frame_off, self.frame_hw = frames, frame_off, frame_hw
+        self.masks, self.mask_off, self.mask_ndim = masks, mask_off, mask_ndim
+
+
+class PredicateModel(nn.Module):
+    def __init__(self, hidden_dim=None, num_top_pairs=None, device="cuda", model_name="openai/clip-vit-base-patch32",
+                 tokenizer=None, config: Optional[ClipConfig] = None, init_seed: Optional[int] = None):
+        """hidden_dim / num_top_pairs are accepted and unused, as in the reference (:11).
+        Weights: pretrained checkpoints cannot be fetched here; load them with
+        `load_state_dict` (keys `clip_{cate,unary,binary}_model.*`).  `init_seed`
+        fills the three towers with seeded random weights instead."""
+        super().__init__()
+        _lib.load()  # fail loudly when the HIP extension is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("laser_amd.PredicateModel needs an MI355X: no GPU is visible and there is no CPU path")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"laser_amd.PredicateModel runs on a GPU device, got {device!r}")
+        self.cfg = config or config_by_name(model_name)
+        self.num_top_pairs = num_top_pairs
+        self.use_sparse = False
+        if tokenizer is None:
+            tokenizer = self._default_tokenizer(model_name)
+        self.clip_tokenizer = tokenizer
+        if getattr(self.clip_tokenizer, "pad_token", None) is None:
+            self.clip_tokenizer.pad_token = self.clip_tokenizer.unk_token if self.clip_tokenizer.unk_token else self.clip_tokenizer.eos_token
+        seed = 0 if init_seed is None else init_seed
+        for k, prefix in enumerate(TOWER_PREFIXES):
+            self.add_module(prefix, _ParamTree(random_state_dict(self.cfg, seed * 1000 + k), self.device))
+        self._towers = None          # packed device blobs, rebuilt when weights change
+        self._text_cache: Dict = {}
+        self.cache_text_features = True
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed_weights())
+
+    # -- weights ---------------------------------------------------------------
+    def _default_tokenizer(self, model_name):
+        try:
+            from transformers import AutoTokenizer
+            return AutoTokenizer.from_pretrained(model_name, local_files_only=True)
+        except Exception as e:  # no vocabulary files on this machine
+            from .tokenizer import HashTokenizer
+            warnings.warn(f"CLIP tokenizer files for {model_name!r} are not available ({type(e).__name__}); "
+                          f"falling back to the deterministic HashTokenizer")
+            return HashTokenizer(self.cfg.vocab, self.cfg.bos_token_id, self.cfg.eos_token_id)
+
+    def invalidate_packed_weights(self):
+        self._towers = None
+        self._text_cache = {}
+
+    def _packed(self):
+        if self._towers is None:
+            towers = {}
+            for prefix in TOWER_PREFIXES:
+                sd = {k: v.detach() for k, v in self._modules[prefix].state_dict().items()}
+                towers[prefix] = (ops.Tower(self.cfg, "vision", sd, self.device), ops.Tower(self.cfg, "text", sd, self.device),
+                                  float(sd["logit_scale"].exp()))
+            self._towers = towers
+        return self._towers
+
+    # -- inputs ----------------------------------------------------------------
+    def stage_inputs(self, batched_videos, batched_masks) -> DeviceInputs:
+        """Upload frames (u8[H,W,3]) and masks (anything `.astype(bool)` accepts, [H,W,1]
+        or [H,W]) into two flat device buffers."""
+        frame_off, frame_hw, chunks, off = [], [], [], 0
+        for f in batched_videos:
+            f = np.ascontiguousarray(f)
+            if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3:
+                raise ValueError(f"frames must be uint8 [H,W,3], got {f.dtype} {f.shape}")
+            frame_off.append(off); frame_hw.append((f.shape[0], f.shape[1])); chunks.append(f.reshape(-1))
+            off += f.size
+        chunks.append(np.zeros(ops.PAD, dtype=np.uint8))
+        frames = torch.from_numpy(np.concatenate(chunks)).to(self.device, non_blocking=True)
+        mask_off, mask_ndim, mchunks, off = [], [], [], 0
+        for m in batched_masks:
+            m = np.asarray(m)
+            mask_ndim.append(m.ndim)
+            if m.ndim == 3:
+                if m.shape[2] != 1:
+                    raise ValueError(f"masks must be [H,W,1] or [H,W], got {m.shape}")
+                m = m[:, :, 0]
+            m = np.ascontiguousarray(m.astype(bool)).view(np.uint8)
+            mask_off.append(off); mchunks.append(m.reshape(-1))
+            off += m.size
+        masks = None
+        if mchunks:
+            mchunks.append(np.zeros(ops.PAD, dtype=np.uint8))
+            masks = torch.from_numpy(np.concatenate(mchunks)).to(self.device, non_blocking=True)
+        return DeviceInputs(frames, frame_off, frame_hw, masks, mask_off, mask_ndim)
+
+    def _text_features(self, prefix: str, kws: Sequence[str]) -> torch.Tensor:
+        key = (prefix, tuple(kws))
+        if self.cache_text_features and not self.training and key in self._text_cache:
+            return self._text_cache[key]
+        tokens = self.clip_tokenizer(list(kws), return_tensors="pt", max_length=75, truncation=True, padding="max_length")
+        ids = tokens["input_ids"]
+        am = tokens.get("attention_mask") if hasattr(tokens, "get") else tokens["attention_mask"]
+        feats = self._packed()[prefix][1].encode_text(ids, am)
+        if self.cache_text_features and not self.training:
+            self._text_cache[key] = feats
+        return feats
+
+    def _crops(self, dev_in: DeviceInputs, table: np.ndarray, alpha, white_alpha) -> torch.Tensor:
+        cfg = self.cfg
+        return ops.crop_preprocess(dev_in.frames, dev_in.masks, table, cfg.image, layout=_lib.LAYOUT_PATCHES,
+                                   patch=cfg.patch, out_dtype=_lib.DTYPE_BF16, alpha=alpha, white_alpha=white_alpha)
+
+    # -- forward ---------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, batched_video_ids, batched_videos, batched_masks, batched_bboxes, batched_names,
+                batched_object_ids, batched_unary_kws, batched_binary_kws, batched_obj_pairs, batched_video_splits,
+                batched_binary_predicates, unary_segment_size=None, binary_segment_size=None, alpha=0.5,
+                white_alpha=0.8, topk_cate=3, dummy_str="$$$", multi_class=False, output_logit=False,
+                output_embeddings=False, device_inputs: Optional[DeviceInputs] = None):
+        towers = self._packed()
+        dev = self.device
+        B = len(batched_video_ids)
+
+        def fill_empty(batched_kw):
+            return [list(kw) if len(kw) else [dummy_str] for kw in batched_kw]
+
+        batched_names = fill_empty(batched_names)
+        batched_unary_kws = fill_empty(batched_unary_kws)
+        batched_binary_kws = fill_empty(batched_binary_kws)
+        dummy_terms: List[torch.Tensor] = []
+
+        # Step 1: text features of the three vocabularies (:137-186)
+        name_feats = [self._text_features("clip_cate_model", n) for n in batched_names]
+        unary_feats = [self._text_features("clip_unary_model", n) for n in batched_unary_kws]
+        binary_feats = [self._text_features("clip_binary_model", n) for n in batched_binary_kws]
+
+        # Step 2: object crop table (:188-217)
+        splits = [0] + list(batched_video_splits)
+        assert len(batched_object_ids) > 0, f"No object bbox: {batched_video_ids}"
+        if device_inputs is None:
+            device_inputs = self.stage_inputs(batched_videos, batched_masks)
+        di = device_inputs
+        obj_index = {}                                   # (vid, fid, oid) -> position in batched_object_ids
+        ids_lookup: Dict[int, list] = {v: [] for v in range(B)}
+        per_vid_rows: Dict[int, list] = {v: [] for v in range(B)}
+        for pos, ((vid, fid, oid), bbox) in enumerate(zip(batched_object_ids, batched_bboxes)):
+            if pos >= len(di.mask_off):
+                break                                    # zip() in the reference stops at the shortest list
+            fidx = splits[vid] + fid
+            H, W = di.frame_hw[fidx]
+            x1, y1, x2, y2 = resolve_union_box([bbox], batched_video_ids)
+            xa, ya, xb, yb = slice_box(x1, y1, x2, y2, W, H, batched_video_ids)
+            per_vid_rows[vid].append((di.frame_off[fidx], di.mask_off[pos], -1, W, H, xa, ya, xb, yb, _lib.CROP_OBJECT, 0))
+            obj_index[(vid, fid, oid)] = pos
+            ids_lookup[vid].append((fid, oid))
+        obj_rows = [r for v in range(B) for r in per_vid_rows[v]]
+        obj_start = np.cumsum([0] + [len(per_vid_rows[v]) for v in range(B)])
+        obj_table = np.array(obj_rows, dtype=CROP_DTYPE)
+        n_obj = len(obj_rows)
+
+        # Step 3: object crops through the category and unary towers (:233-339)
+        cate_feat = unary_feat = None
+        if n_obj:
+            patches = self._crops(di, obj_table, alpha, white_alpha)
+            cate_feat = towers["clip_cate_model"][0].encode_images(patches, n_obj)
+            unary_feat = towers["clip_unary_model"][0].encode_images(patches, n_obj)
+        sim_mode = _lib.SIM_LOGIT if output_logit else _lib.SIM_SOFTMAX
+
+        cate_out: Dict[int, object] = {v: {} for v in range(B)}
+        unary_out: Dict[int, object] = {v: {} for v in range(B)}
+        cate_feats_out: Dict[int, object] = {v: {} for v in range(B)}
+        unary_feats_out: Dict[int, object] = {v: {} for v in range(B)}
+        obj_per_cate_all: Dict[int, dict] = {v: {} for v in range(B)}
+        need_ranking = batched_binary_predicates[0] is not None
+        # the reference zips this loop with batched_binary_predicates (:233-238)
+        for vid in range(min(B, len(batched_binary_predicates))):
+            s, e = int(obj_start[vid]), int(obj_start[vid + 1])
+            object_ids = ids_lookup[vid]
+            if e > s:
+                cf, uf = cate_feat[s:e], unary_feat[s:e]
+            else:
+                cf = uf = torch.tensor([])
+            cate_feats_out[vid], unary_feats_out[vid] = cf, uf
+            names, ukws = batched_names[vid], batched_unary_kws[vid]
+            if e > s:
+                cate_dense = ops.similarity(name_feats[vid], cf, towers["clip_cate_model"][2], sim_mode)
+                unary_dense = ops.similarity(unary_feats[vid], uf, towers["clip_unary_model"][2], sim_mode)
+                for r, nm in enumerate(names):
+                    if nm == dummy_str:
+                        dummy_terms.append(cate_dense[r].sum())
+                for r, nm in enumerate(ukws):
+                    if nm == dummy_str:
+                        dummy_terms.append(unary_dense[r].sum())
+                # per-object mean over frames (:296-311); groups in order of first appearance
+                group_of, oids = {}, []
+                for (_, oid) in object_ids:
+                    if oid not in group_of:
+                        group_of[oid] = len(oids)
+                        oids.append(oid)
+                seg = torch.tensor([group_of[oid] for (_, oid) in object_ids], dtype=torch.int32)
+                cate_mean = ops.segment_mean(cate_dense, seg, len(oids))
+                # a name listed twice pools both rows' probabilities into one mean in the reference (:296-311)
+                uniq: Dict[str, list] = {}
+                for r, nm in enumerate(names):
+                    if nm != dummy_str:
+                        uniq.setdefault(nm, []).append(r)
+                if any(len(rs) > 1 for rs in uniq.values()):
+                    cate_mean = torch.stack([cate_mean[rs].mean(dim=0) for rs in uniq.values()])
+                    c_rows = list(enumerate(uniq.keys()))
+                else:
+                    c_rows = [(r, nm) for r, nm in enumerate(names) if nm != dummy_str]
+                cate_out[vid] = ProbDict(cate_mean, c_rows, list(enumerate(oids)), lambda oid, nm: (oid, nm), "col_major")
+                u_rows = [(r, nm) for r, nm in enumerate(ukws) if nm != dummy_str]
+                unary_out[vid] = ProbDict(unary_dense, u_rows, list(enumerate(object_ids)),
+                                          lambda fo, nm: (fo[0], fo[1], nm), "row_major")
+                if need_ranking:
+                    host = cate_mean.cpu()
+                    # per category: (prob, oid) sorted descending, ties by descending oid (:313-314)
+                    obj_per_cate_all[vid] = {nm: sorted([(float(host[r, g]), oid) for g, oid in enumerate(oids)], reverse=True)
+                                             for r, nm in c_rows}
+
+        # Step 4: pair selection (:342-392)
+        pair_lookup: Dict[int, dict] = {v: {} for v in range(B)}
+        for (vid, fid, (a, b)) in batched_obj_pairs:
+            pair_lookup[vid].setdefault((a, b), []).append(fid)
+        if not need_ranking:
+            selected = list(batched_obj_pairs)
+        else:
+            sel = set()
+            for bp_vid, preds in enumerate(batched_binary_predicates):
+                cands = {nm: [oid for _, oid in lst[:topk_cate]] for nm, lst in obj_per_cate_all[bp_vid].items()}
+                for (rel_name, from_name, to_name) in preds:
+                    if from_name in cands and to_name in cands:
+                        for a in cands[from_name]:
+                            for b in cands[to_name]:
+                                if (a, b) in pair_lookup[bp_vid]:
+                                    for fid in pair_lookup[bp_vid][(a, b)]:
+                                        sel.add((bp_vid, fid, (a, b)))
+            selected = list(sel)
+        new_select: Dict[int, list] = {v: [] for v in range(B)}
+        pair_rows: Dict[int, list] = {v: [] for v in range(B)}
+        for (vid, fid, (a, b)) in selected:
+            new_select[vid].append((vid, fid, (a, b)))
+            fidx = splits[vid] + fid
+            H, W = di.frame_hw[fidx]
+            pa, pb = obj_index[(vid, fid, a)], obj_index[(vid, fid, b)]   # KeyError as in the reference (:399-400)
+            if di.mask_ndim[pa] != 3 or di.mask_ndim[pb] != 3:
+                raise IndexError("too many indices for array: pair masks must be 3-dimensional [H,W,1]")
+            x1, y1, x2, y2 = resolve_union_box([batched_bboxes[pa], batched_bboxes[pb]], batched_video_ids)
+            xa, ya, xb, yb = slice_box(x1, y1, x2, y2, W, H, batched_video_ids)
+            pair_rows[vid].append((di.frame_off[fidx], di.mask_off[pa], di.mask_off[pb], W, H, xa, ya, xb, yb,
+                                   _lib.CROP_PAIR, 0))
+        if len(selected) == 0:                          # default image when no pair exists (:416-420)
+            selected.append((0, -1, (-1, -1)))
+            new_select[0] = [(0, -1, (-1, -1))]
+            H, W = di.frame_hw[0]
+            pair_rows[0] = [(di.frame_off[0], -1, -1, W, H, 0, 0, W, H, _lib.CROP_PLAIN, 0)]
+        all_pair_rows = [r for v in range(B) for r in pair_rows[v]]
+        pair_start = np.cumsum([0] + [len(pair_rows[v]) for v in range(B)])
+        n_pair = len(all_pair_rows)
+        pair_feat = None
+        if n_pair:
+            ppatches = self._crops(di, np.array(all_pair_rows, dtype=CROP_DTYPE), alpha, white_alpha)
+            pair_feat = towers["clip_binary_model"][0].encode_images(ppatches, n_pair)
+
+        binary_out: List[object] = []
+        pair_feats_out: Dict[int, object] = {v: torch.tensor([]) for v in range(B)}
+        if output_logit:
+            bmode = _lib.SIM_LOGIT
+        else:
+            bmode = _lib.SIM_SIGMOID if multi_class else _lib.SIM_SOFTMAX
+        for vid in range(B):
+            s, e = int(pair_start[vid]), int(pair_start[vid + 1])
+            if e == s:
+                binary_out.append({})
+                continue
+            pf = pair_feat[s:e]
+            pair_feats_out[vid] = pf
+            bkws = batched_binary_kws[vid]
+            dense = ops.similarity(binary_feats[vid], pf, towers["clip_binary_model"][2], bmode)
+            cols = []
+            for c, (_, fid, pr) in enumerate(new_select[vid]):
+                if fid == -1:
+                    for r, nm in enumerate(bkws):
+                        if nm != dummy_str:
+                            dummy_terms.append(dense[r, c])
+                else:
+                    cols.append((c, (fid, pr)))
+            for r, nm in enumerate(bkws):
+                if nm == dummy_str:
+                    dummy_terms.append(dense[r].sum())
+            b_rows = [(r, nm) for r, nm in enumerate(bkws) if nm != dummy_str]
+            binary_out.append(ProbDict(dense, b_rows, cols, lambda fp, nm: (fp[0], fp[1], nm), "row_major"))
+
+        dummy_prob = torch.stack(dummy_terms).sum() if dummy_terms else torch.tensor(0.0, device=dev)
+        if output_embeddings:
+            emb = {"cate_obj_clip_features": cate_feats_out, "cate_object_ids": ids_lookup,
+                   "unary_obj_clip_features": unary_feats_out, "unary_object_ids": ids_lookup,
+                   "binary_obj_pair_features": pair_feats_out, "binary_object_pairs": new_select}
+            return cate_out, unary_out, binary_out, dummy_prob, emb
+        return cate_out, unary_out, binary_out, dummy_prob

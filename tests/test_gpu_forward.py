@@ -1,0 +1,91 @@
+"""GPU parity tests of the full scoring path: laser_amd.PredicateModel.forward
+against the golden outputs of the reference's forward() (tests/golden) and
+against the CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): crop boxes / pair indices / key order
+bit-exact; probabilities within 2e-2 max-abs under bf16; >= 99 % top-1 agreement."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cases import FORWARD_CASES, build_case_batch  # noqa: E402
+from golden_io import compare_prob_dicts, load_forward_case  # noqa: E402
+
+from laser_amd.config import config_by_name  # noqa: E402
+from laser_amd.predicate_model import PredicateModel  # noqa: E402
+from laser_amd.tokenizer import HashTokenizer  # noqa: E402
+from laser_amd.weights import predicate_model_state_dict  # noqa: E402
+
+PROB_TOL = 2e-2
+
+
+def _model(cfg_name, wseed):
+    cfg = config_by_name(cfg_name)
+    tok = HashTokenizer(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    m = PredicateModel(None, None, "cuda:0", cfg_name, tokenizer=tok).eval()
+    m.load_state_dict(predicate_model_state_dict(cfg, wseed, float(np.log(100.0))))
+    return m
+
+
+def _top1_agreement(got_dense_cols, want_dense_cols):
+    return float((got_dense_cols.argmax(0) == want_dense_cols.argmax(0)).float().mean())
+
+
+@pytest.mark.parametrize("name", list(FORWARD_CASES))
+def test_forward_matches_reference_golden(name):
+    cfg_name, wseed, _, fk = FORWARD_CASES[name]
+    rec, cate, unary, binary, dummy, z = load_forward_case(name)
+    model = _model(cfg_name, wseed)
+    out = model(**build_case_batch(name).forward_kwargs(), **fk)
+    torch.cuda.synchronize()
+    tol = 0.25 if fk.get("output_logit") else PROB_TOL     # logits are scaled by 100
+    assert set(out[0].keys()) == set(cate.keys())
+    worst = 0.0
+    for v in cate:
+        worst = max(worst, compare_prob_dicts(out[0][v], cate[v], tol))
+        worst = max(worst, compare_prob_dicts(out[1][v], unary[v], tol))
+    assert len(out[2]) == len(binary)
+    for g, w in zip(out[2], binary):
+        worst = max(worst, compare_prob_dicts(g, w, tol))
+    assert abs(float(out[3]) - dummy) <= max(tol, 1e-3 * abs(dummy))
+    if fk.get("output_embeddings"):
+        emb = out[4]
+        assert [tuple(x) for x in rec["cate_object_ids"]["0"]] == list(emb["cate_object_ids"][0])
+        assert [(p[0], p[1], tuple(p[2])) for p in rec["binary_object_pairs"]["0"]] == list(emb["binary_object_pairs"][0])
+        for nm in ("cate_obj_clip_features", "unary_obj_clip_features", "binary_obj_pair_features"):
+            got, want = emb[nm][0].float().cpu().numpy(), z[f"{nm}_0"]
+            cos = (got * want).sum(-1) / (np.linalg.norm(got, axis=-1) * np.linalg.norm(want, axis=-1))
+            assert cos.min() > 0.999, (nm, cos.min())
+    print(f"{name}: max |p - reference| = {worst:.3e}")
+
+
+def test_top1_agreement_b32():
+    """>= 99 % top-1 predicate agreement with the fp32 oracle on a B/32 clip."""
+    from oracle.forward_ref import OraclePredicateModel
+    from laser_amd.synthetic import make_clip_batch
+    from laser_amd.weights import split_predicate_state_dict
+    cfg = config_by_name("vit-b-32")
+    sd = predicate_model_state_dict(cfg, 5, float(np.log(100.0)))
+    tok = HashTokenizer(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    model = PredicateModel(None, None, "cuda:0", "vit-b-32", tokenizer=tok).eval()
+    model.load_state_dict(sd)
+    b = make_clip_batch(2, n_videos=1, frames=3, objects=5, H=360, W=480, k_cate=12, k_unary=40, k_binary=20,
+                        min_box=16, max_box=300)
+    got = model(**b.forward_kwargs())
+    torch.set_num_threads(16)
+    want = OraclePredicateModel(cfg, split_predicate_state_dict(sd), tok)(**b.forward_kwargs())
+    worst, agree, total = 0.0, 0, 0
+    for g, w in ((got[1][0], want[1][0]), (got[2][0], want[2][0])):
+        assert list(g.keys()) == list(w.keys())
+        gv = g.values_tensor().cpu().numpy()
+        wv = np.array([float(x) for x in w.values()])
+        worst = max(worst, float(np.abs(gv - wv).max()))
+        K = len({k[-1] for k in w})
+        gv, wv = gv.reshape(K, -1), wv.reshape(K, -1)        # name-major key order
+        agree += int((gv.argmax(0) == wv.argmax(0)).sum())
+        total += gv.shape[1]
+    assert worst <= PROB_TOL, worst
+    assert agree / total >= 0.99, (agree, total)
+    print(f"b32: max |p - oracle| = {worst:.3e}, top-1 agreement {agree}/{total}")
