@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the SGCLIP scoring path on MI355X.
+
+Metric (BASELINE.json): object+pair crops scored per second.  One "crop scored"
+is one object crop or one ordered-pair crop taken through
+crop/blend/resize/normalize -> CLIP ViT encode (object crops through the
+category AND the unary tower, pair crops through the binary tower) -> cosine
+similarity against the vocabulary -> softmax.  Workload = BASELINE.json
+configs[1]: one synthetic clip of 32 frames x 16 objects (240 ordered pairs per
+frame), 224^2 crops, 35 category + 200 unary + 50 binary keywords, ViT-B/32,
+bf16 MFMA with fp32 accumulation.  A step scores one clip per GPU (8 192 crops,
+8 704 image encodes, 285 text encodes); frames, masks, crop tables and weights
+are resident in HBM when the timed region starts.  With N > 1 every rank scores
+its own clip (weak scaling, clips are independent) and the dense probability
+blocks are all-gathered over RCCL each step.
+
+Usage: python bench.py --gpus N --steps K --warmup W   (N > 1: launch with
+python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from laser_amd import _lib, ops  # noqa: E402
+from laser_amd.config import config_by_name  # noqa: E402
+from laser_amd.predicate_model import CROP_DTYPE, PredicateModel, resolve_union_box, slice_box  # noqa: E402
+from laser_amd.synthetic import make_clip_batch  # noqa: E402
+from laser_amd.tokenizer import HashTokenizer  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak
+MFMA_PEAK_TFLOPS = 2500.0    # MI355X dense bf16 MFMA spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="vit-b-32")
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--objects", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=240)
+    return ap.parse_args()
+
+
+class ClipPlan:
+    """One synthetic clip staged in HBM: frames, masks, crop tables, token ids."""
+
+    def __init__(self, model: PredicateModel, batch, device):
+        cfg = model.cfg
+        self.batch = batch
+        self.di = model.stage_inputs(batch.batched_videos, batch.batched_masks)
+        di = self.di
+        rows, index = [], {}
+        for pos, ((vid, fid, oid), bbox) in enumerate(zip(batch.batched_object_ids, batch.batched_bboxes)):
+            H, W = di.frame_hw[fid]
+            xa, ya, xb, yb = slice_box(*resolve_union_box([bbox]), W, H)
+            rows.append((di.frame_off[fid], di.mask_off[pos], -1, W, H, xa, ya, xb, yb, _lib.CROP_OBJECT, 0))
+            index[(fid, oid)] = pos
+        self.obj_table = np.array(rows, dtype=CROP_DTYPE)
+        rows = []
+        for (vid, fid, (a, b)) in batch.batched_obj_pairs:
+            H, W = di.frame_hw[fid]
+            pa, pb = index[(fid, a)], index[(fid, b)]
+            xa, ya, xb, yb = slice_box(*resolve_union_box([batch.batched_bboxes[pa], batch.batched_bboxes[pb]]), W, H)
+            rows.append((di.frame_off[fid], di.mask_off[pa], di.mask_off[pb], W, H, xa, ya, xb, yb, _lib.CROP_PAIR, 0))
+        self.pair_table = np.array(rows, dtype=CROP_DTYPE)
+        self.n_obj, self.n_pair = len(self.obj_table), len(self.pair_table)
+        up = lambda t: torch.from_numpy(t.view(np.uint8).reshape(-1).copy()).to(device)
+        self.obj_dev, self.pair_dev = up(self.obj_table), up(self.pair_table)
+        P, kpad = cfg.n_patches, _lib.load().sgclip_patch_kpad(cfg.patch)
+        self.obj_patches = torch.zeros((self.n_obj * P, kpad), dtype=torch.bfloat16, device=device)
+        self.pair_patches = torch.zeros((self.n_pair * P, kpad), dtype=torch.bfloat16, device=device)
+        tok = model.clip_tokenizer
+        self.tokens = []
+        for kws in (batch.batched_names[0], batch.batched_unary_kws[0], batch.batched_binary_kws[0]):
+            t = tok(list(kws), return_tensors="pt", max_length=75, truncation=True, padding="max_length")
+            self.tokens.append((t["input_ids"].to(device, torch.int32), t["attention_mask"].to(device, torch.int32)))
+        self.seg = torch.tensor([oid for (_, _, oid) in batch.batched_object_ids], dtype=torch.int32, device=device)
+        self.n_groups = int(self.seg.max()) + 1
+        self.algo_crop_bytes = 0.0
+        for tab, m in ((self.obj_table, 1), (self.pair_table, 2)):
+            wh = (tab["x2"] - tab["x1"]).astype(np.float64) * (tab["y2"] - tab["y1"])
+            self.algo_crop_bytes += float(((3 + m) * wh + 2 * 3 * cfg.image * cfg.image).sum())
+
+
+def score_clip(model: PredicateModel, plan: ClipPlan):
+    """The device pipeline of PredicateModel.forward for one clip (inference path)."""
+    towers = model._packed()
+    cfg = model.cfg
+    (cv, ct, cs), (uv, ut, us), (bv, bt, bs) = (towers[p] for p in ("clip_cate_model", "clip_unary_model", "clip_binary_model"))
+    tf_c = ct.encode_text(*plan.tokens[0])
+    tf_u = ut.encode_text(*plan.tokens[1])
+    tf_b = bt.encode_text(*plan.tokens[2])
+    kw = dict(layout=_lib.LAYOUT_PATCHES, patch=cfg.patch, out_dtype=_lib.DTYPE_BF16, entries_dev_ready=True)
+    po = ops.crop_preprocess(plan.di.frames, plan.di.masks, plan.obj_table, cfg.image, out=plan.obj_patches,
+                             entries_dev=plan.obj_dev, **kw)
+    cf = cv.encode_images(po, plan.n_obj)
+    uf = uv.encode_images(po, plan.n_obj)
+    pp = ops.crop_preprocess(plan.di.frames, plan.di.masks, plan.pair_table, cfg.image, out=plan.pair_patches,
+                             entries_dev=plan.pair_dev, **kw)
+    pf = bv.encode_images(pp, plan.n_pair)
+    cate = ops.similarity(tf_c, cf, cs, _lib.SIM_SOFTMAX)
+    unary = ops.similarity(tf_u, uf, us, _lib.SIM_SOFTMAX)
+    binary = ops.similarity(tf_b, pf, bs, _lib.SIM_SOFTMAX)
+    cate_mean = ops.segment_mean(cate, plan.seg, plan.n_groups)
+    return cate_mean, unary, binary
+
+
+def timing_read(kind):
+    lib = _lib.load()
+    ms, n, work = C.c_double(), C.c_int64(), C.c_double()
+    _lib.check(lib.sgclip_timing_read(kind, C.byref(ms), C.byref(n), C.byref(work)))
+    return ms.value, n.value, work.value
+
+
+def cpu_baseline(args, cfg, sd, tok, batch):
+    """The CPU oracle (a port of the reference path) on a bounded sample of the same clip:
+    frame 0 with all its objects and the first --cpu-sample-pairs pairs."""
+    from laser_amd.weights import split_predicate_state_dict
+    from oracle.forward_ref import OraclePredicateModel
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    O = args.objects
+    kw = batch.forward_kwargs()
+    kw["batched_videos"] = kw["batched_videos"][:1]
+    kw["batched_masks"] = kw["batched_masks"][:O]
+    kw["batched_bboxes"] = kw["batched_bboxes"][:O]
+    kw["batched_object_ids"] = kw["batched_object_ids"][:O]
+    kw["batched_obj_pairs"] = [p for p in kw["batched_obj_pairs"] if p[1] == 0][: args.cpu_sample_pairs]
+    kw["batched_video_splits"] = [1]
+    oracle = OraclePredicateModel(cfg, split_predicate_state_dict(sd), tok)
+    t0 = time.perf_counter()
+    oracle(**kw)
+    dt = time.perf_counter() - t0
+    crops = O + len(kw["batched_obj_pairs"])
+    # the text towers run once per forward (per clip), the rest scales with the frames:
+    # clip estimate = text + frames * (frame-0 time without text), crops scaled the same way
+    t_text = oracle.timers["text"]
+    per_frame = dt - t_text
+    clip_s = t_text + args.frames * per_frame
+    return {"value": args.frames * crops / clip_s, "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"frame 0 of the same clip: {O} object crops (2 encodes each) + {len(kw['batched_obj_pairs'])} pair crops "
+                      f"in {per_frame:.1f} s, plus the once-per-clip text encode of "
+                      f"{len(kw['batched_names'][0]) + len(kw['batched_unary_kws'][0]) + len(kw['batched_binary_kws'][0])} keywords "
+                      f"in {t_text:.1f} s; clip rate = {args.frames} x crops / (text + {args.frames} x frame time); fp32 torch CPU",
+            "stage_seconds": {k: round(v, 3) for k, v in oracle.timers.items()}}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = config_by_name(args.model)
+    tok = HashTokenizer(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    model = PredicateModel(None, None, device, args.model, tokenizer=tok, init_seed=7).eval()
+    for p in ("clip_cate_model", "clip_unary_model", "clip_binary_model"):
+        model._modules[p].logit_scale.data.fill_(float(np.log(100.0)))
+    model.invalidate_packed_weights()
+    # every rank scores its own clip (different seed); frame pixels come from a pool of 4 distinct frames
+    batch = make_clip_batch(100 + rank, n_videos=1, frames=args.frames, objects=args.objects, distinct_frames=4)
+    plan = ClipPlan(model, batch, device)
+    crops_per_step = plan.n_obj + plan.n_pair
+    encodes_per_step = 2 * plan.n_obj + plan.n_pair
+
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        cate_mean, unary, binary = score_clip(model, plan)
+        if dist is not None:
+            flat = torch.cat([cate_mean.reshape(-1), unary.reshape(-1), binary.reshape(-1)])
+            if gathered is None:
+                gathered = torch.empty(world * flat.numel(), dtype=flat.dtype, device=device)
+            dist.all_gather_into_tensor(gathered, flat)
+        return cate_mean, unary, binary
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * crops_per_step * args.steps / elapsed
+
+    # per-kernel durations, live, with HIP events on the launch stream (separate pass so
+    # that event recording does not perturb the number above)
+    lib = _lib.load()
+    _lib.check(lib.sgclip_timing_enable(1, 4096))
+    tsteps = min(args.steps, 2)
+    for _ in range(tsteps):
+        step()
+    torch.cuda.synchronize()
+    kinds = {k: timing_read(k) for k in (0, 1, 2, 3, 8, 9)}
+    _lib.check(lib.sgclip_timing_enable(0, 0))
+    g_ms = sum(kinds[k][0] for k in (0, 1, 2, 3))
+    g_n = sum(kinds[k][1] for k in (0, 1, 2, 3))
+    g_fl = sum(kinds[k][2] for k in (0, 1, 2, 3))
+    gemm_tflops = g_fl / (g_ms * 1e-3) / 1e12 if g_ms else 0.0
+    crop_ms, crop_n, crop_bytes = kinds[8]
+    crop_gbs = crop_bytes / (crop_ms * 1e-3) / 1e9 if crop_ms else 0.0
+    step_ms_timed = {"gemm": g_ms / tsteps, "attention": kinds[9][0] / tsteps, "crop": crop_ms / tsteps}
+
+    result = {
+        "metric": "object+pair crops scored/sec", "value": value, "unit": "crops/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"synthetic clip {args.frames} frames x {args.objects} objects x {args.objects * (args.objects - 1)} "
+                               f"ordered pairs/frame at 1280x720, {cfg.image}^2 crops, 35 category + 200 unary + 50 binary "
+                               f"keywords, {args.model}, one clip per GPU per step, random-init weights",
+                   "crops_per_step_per_gpu": crops_per_step, "image_encodes_per_step_per_gpu": encodes_per_step,
+                   "text_encodes_per_step_per_gpu": 285, "parallelism": f"dp{world} (clips)"},
+        "frames_per_s": world * args.frames * args.steps / elapsed,
+        "clip_latency_ms": ms_per_step,
+        "roofline": {"kernel": "sgclip::gemm_kernel (bf16 MFMA GEMMs of the three ViT towers + text towers, all epilogues)",
+                     "bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": gemm_tflops / MFMA_PEAK_TFLOPS, "traffic": None,
+                     "launches_per_step": g_n / tsteps, "avg_launch_ms": g_ms / max(g_n, 1)},
+        "roofline_crop": {"kernel": "sgclip::crop_kernel", "bound": "hbm", "achieved": crop_gbs, "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": crop_gbs / HBM_PEAK_GBS, "traffic": None,
+                          "avg_launch_ms": crop_ms / max(crop_n, 1), "algorithmic_bytes_per_step": plan.algo_crop_bytes},
+        "kernel_ms_per_step": step_ms_timed,
+        "whole_step_tflops": encodes_per_step * cfg.vit_flops_per_encode() / (ms_per_step * 1e-3) / 1e12,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        result["cpu_baseline"] = cpu_baseline(args, cfg, sd, tok, batch)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

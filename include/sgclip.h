@@ -35,6 +35,14 @@ extern "C" {
 int sgclip_abi_version(void);
 const char *sgclip_last_error(void);
 
+/* Opt-in per-kernel timing for benchmarks (no counterpart in the reference).  While
+ * enabled, every launch of a timed kernel is bracketed by two HIP events on its launch
+ * stream.  kind: 0..4 = sgclip_gemm_bf16 by epilogue, 8 = crop, 9 = attention.
+ * sgclip_timing_read waits for the recorded events and returns the summed duration,
+ * launch count and summed algorithmic work (FLOPs for GEMM/attention, bytes for crop). */
+int sgclip_timing_enable(int on, int max_records);
+int sgclip_timing_read(int kind, double *total_ms, int64_t *launches, double *work);
+
 /* ------------------------------------------------------------------------
  * (1) mask-guided crop + resize + normalize.
  *

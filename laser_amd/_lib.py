@@ -42,6 +42,8 @@ class TowerDesc(C.Structure):
 SIGNATURES = {
     "sgclip_abi_version": (C.c_int, []),
     "sgclip_last_error": (C.c_char_p, []),
+    "sgclip_timing_enable": (C.c_int, [C.c_int, C.c_int]),
+    "sgclip_timing_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "sgclip_crop_preprocess": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_void_p, C.c_void_p]),

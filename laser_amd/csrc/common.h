@@ -22,6 +22,16 @@ namespace sgclip {
 void set_error(const char *fmt, ...);
 int launch_check(const char *what);
 
+// Opt-in per-kernel timing (sgclip_timing_*): when enabled, a KernelTimer in a launch
+// function brackets the launch with two HIP events on the launch stream.
+enum { TK_GEMM0 = 0, TK_CROP = 8, TK_ATTN = 9, TK_LN = 10, TK_SIM = 11, TK_COUNT = 12 };
+struct KernelTimer {
+    KernelTimer(int kind, double work, hipStream_t stream);
+    ~KernelTimer();
+    int slot;
+    hipStream_t stream;
+};
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -190,6 +190,7 @@ extern "C" int sgclip_attention(const void *qkv_dev, void *out_dev, int n_seq, i
         set_error("sgclip_attention: grid too large");
         return SGCLIP_EINVAL;
     }
+    KernelTimer timer(TK_ATTN, 4.0 * n_seq * heads * (double)T * T * 64, stream);
     hipLaunchKernelGGL(attn_kernel, dim3((unsigned)blocks), dim3(ATT_WAVES * 64), 0, stream, a);
     return launch_check("sgclip_attention");
 }

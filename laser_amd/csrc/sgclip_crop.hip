@@ -391,6 +391,7 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
         return SGCLIP_EINVAL;
     }
     int ksx = 1, ksy = 1, wn_cap = 1;
+    double algo_bytes = 0;  // per crop: 3hw frame + m*hw mask + out
     for (int i = 0; i < n_crops; i++) {
         const sgclip_crop_t &c = crops[i];
         const int w = c.x2 - c.x1, h = c.y2 - c.y1;
@@ -414,6 +415,8 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
             set_error("sgclip_crop_preprocess: crop %d has unknown mode %d", i, c.mode);
             return SGCLIP_EINVAL;
         }
+        algo_bytes += (3.0 + (c.mode == SGCLIP_CROP_PAIR ? 2 : (c.mode == SGCLIP_CROP_OBJECT ? 1 : 0))) * w * h +
+                      3.0 * S * S * (out_dtype == SGCLIP_DTYPE_BF16 ? 2 : 4);
         int new_w, new_h, top, left;
         crop_geom(w, h, S, new_w, new_h, top, left);
         ksx = std::max(ksx, axis_ksize(w, new_w));
@@ -456,11 +459,12 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
     a.ksy_cap = ksy;
     a.wn_cap = wn_cap;
     const dim3 grid((unsigned)n_crops * a.nbands), block(NT);
+    KernelTimer timer(TK_CROP, algo_bytes, stream);
     if (S <= NT) {
-        hipFuncSetAttribute((const void *)crop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+        (void)hipFuncSetAttribute((const void *)crop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
         hipLaunchKernelGGL(crop_kernel<1>, grid, block, L.total, stream, a);
     } else {
-        hipFuncSetAttribute((const void *)crop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+        (void)hipFuncSetAttribute((const void *)crop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
         hipLaunchKernelGGL(crop_kernel<2>, grid, block, L.total, stream, a);
     }
     return launch_check("sgclip_crop_preprocess");

@@ -189,6 +189,7 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
     g.tiles_m = ceil_div(M, BM);
     g.tiles_n = ceil_div(N, BN);
     const dim3 grid((unsigned)g.tiles_m * g.tiles_n), block(GEMM_THREADS);
+    KernelTimer timer(TK_GEMM0 + epilogue, 2.0 * M * N * K, stream);
     switch (epilogue) {
         case SGCLIP_EPI_BIAS_BF16: hipLaunchKernelGGL(gemm_kernel<SGCLIP_EPI_BIAS_BF16>, grid, block, 0, stream, g); break;
         case SGCLIP_EPI_BIAS_GELU_BF16: hipLaunchKernelGGL(gemm_kernel<SGCLIP_EPI_BIAS_GELU_BF16>, grid, block, 0, stream, g); break;

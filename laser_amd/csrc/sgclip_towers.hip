@@ -14,6 +14,8 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <vector>
+
 namespace sgclip {
 
 static thread_local char g_err[512] = "";
@@ -32,6 +34,23 @@ int launch_check(const char *what) {
         return SGCLIP_ELAUNCH;
     }
     return SGCLIP_OK;
+}
+
+// ---- opt-in kernel timing ---------------------------------------------------
+struct TimingRec { hipEvent_t a, b; int kind; double work; };
+static bool g_timing = false;
+static std::vector<TimingRec> g_recs;
+static size_t g_used = 0;
+
+KernelTimer::KernelTimer(int kind, double work, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_timing || g_used >= g_recs.size()) return;
+    slot = (int)g_used++;
+    g_recs[slot].kind = kind;
+    g_recs[slot].work = work;
+    (void)hipEventRecord(g_recs[slot].a, stream);
+}
+KernelTimer::~KernelTimer() {
+    if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, stream);
 }
 
 // x[img*T + 0][:] = class_embedding + position_embedding[0]
@@ -211,6 +230,42 @@ static int run_layers(const sgclip_tower_desc_t *t, const TowerPtrs &P, const Wo
 }  // namespace sgclip
 
 using namespace sgclip;
+
+extern "C" int sgclip_timing_enable(int on, int max_records) {
+    if (on && g_recs.empty()) {
+        g_recs.resize(max_records > 0 ? max_records : 65536);
+        for (auto &r : g_recs) {
+            if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+                set_error("sgclip_timing_enable: hipEventCreate failed");
+                return SGCLIP_ELAUNCH;
+            }
+        }
+    }
+    g_timing = on != 0;
+    if (on) g_used = 0;
+    return SGCLIP_OK;
+}
+
+extern "C" int sgclip_timing_read(int kind, double *total_ms, int64_t *launches, double *work) {
+    double ms = 0, w = 0;
+    int64_t n = 0;
+    for (size_t i = 0; i < g_used; i++) {
+        if (g_recs[i].kind != kind) continue;
+        if (hipEventSynchronize(g_recs[i].b) != hipSuccess) {
+            set_error("sgclip_timing_read: event synchronize failed");
+            return SGCLIP_ELAUNCH;
+        }
+        float t = 0;
+        (void)hipEventElapsedTime(&t, g_recs[i].a, g_recs[i].b);
+        ms += t;
+        w += g_recs[i].work;
+        n++;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    if (work) *work = w;
+    return SGCLIP_OK;
+}
 
 extern "C" int sgclip_abi_version(void) { return 1; }
 extern "C" const char *sgclip_last_error(void) { return g_err; }
