@@ -1,25 +1,29 @@
 // bf16 MFMA GEMM for the CLIP towers:  C = epilogue(A[M,K] * W[N,K]^T).
 //
 // Both operands are K-contiguous (activations row-major, nn.Linear weights
-// [out,in]), so A and W tiles are staged identically: 128 rows x 64 k of bf16
-// per tile, written to LDS by global_load_lds_dwordx4 (1 KiB per wave
+// [out,in]), so A and W tiles are staged identically: rows x 64 k of bf16
+// (128 B per row), written to LDS by global_load_lds_dwordx4 (1 KiB per wave
 // instruction = 8 rows x 128 B).  Bank conflicts of the ds_read_b128 fragment
 // reads are removed by an XOR swizzle of the 16-byte chunk index with bits 1..3
 // of the row, applied on the per-lane global SOURCE address (the LDS image of a
 // DMA is lane-linear) and again on the read address.
 //
-// Workgroup = 4 waves (2 x 2), tile 128 x 128, each wave 64 x 64 as 4 x 4
-// v_mfma_f32_16x16x32_bf16 accumulators; double-buffered LDS, one barrier per
-// 64-deep K step with the next tile's DMA issued before the current tile's MFMAs.
+// Main kernel (gemm_ring_kernel): workgroup = 8 waves (4 x 2), tile 256 x 128,
+// each wave 64 x 64 as 4 x 4 v_mfma_f32_16x16x32_bf16 accumulators.  The K loop
+// runs over a 3-slot LDS ring (3 x 48 KiB): the DMA of tile t+2 is issued right
+// after the barrier that retires tile t-1's slot, and the wait before the barrier
+// is a counted s_waitcnt vmcnt(6) that leaves tile t+1's six DMA instructions in
+// flight across it (raw s_barrier, never __syncthreads(), which would drain them).
+// Small problems (M <= 128) use the 128 x 128, 4-wave, 2-slot kernel.
 // Epilogues fuse bias, quick-GELU, the fp32 residual add and the patch-embedding
 // row remap + position embedding.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace sgclip {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int GEMM_THREADS = 256;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int BN = 128, BK = 64;
 
 struct GemmArgs {
     const bf16_t *A;
@@ -31,93 +35,56 @@ struct GemmArgs {
     int M, N, K;
     int aux_rows;
     int tiles_m, tiles_n;
+    int wide_epilogue;  // N % 4 == 0, ldc % 4 == 0 and C, bias, aux 16-byte aligned
 };
 
 // byte offset of 16-byte chunk `c` (0..7) of tile row `row` in the swizzled LDS image
 __device__ __forceinline__ int lds_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
 
-// one operand tile: 16 pieces of 1 KiB, 4 per wave
-__device__ __forceinline__ void stage_tile(const bf16_t *__restrict__ G, int ld, int row0, int max_row, int k0,
-                                           unsigned char *lds_tile, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int piece = wave * 4 + i;
-        const int row = piece * 8 + (lane >> 3);
-        const int pos = lane & 7;
-        const int c = pos ^ ((row >> 1) & 7);
-        int grow = row0 + row;
-        grow = grow < max_row ? grow : max_row - 1;
-        const bf16_t *src = G + (size_t)grow * ld + k0 + c * 8;
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
-    }
+// one 1 KiB piece (8 rows x 128 B) of an operand tile: lane -> (row, swizzled chunk)
+__device__ __forceinline__ void stage_piece(const bf16_t *__restrict__ G, int ld, int row0, int max_row, int k0,
+                                            unsigned char *lds_tile, int piece, int lane) {
+    const int row = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    int grow = row0 + row;
+    grow = grow < max_row ? grow : max_row - 1;
+    const bf16_t *src = G + (size_t)grow * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
 }
 
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
-template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * TILE_BYTES];  // A0 B0 A1 B1
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // XCD-aware remap: blocks that share an XCD (same blockIdx % 8) walk
-    // neighbouring tiles of one A row panel, so the panel stays in that XCD's L2.
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
+// XCD-aware remap: blocks that share an XCD (same blockIdx % 8) walk neighbouring
+// tiles of one A row panel, so the panel stays in that XCD's L2.  Bijective for any grid.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tm = swz / g.tiles_n, tn = swz - tm * g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
 
-    f32x4 acc[4][4];
+// one 64-deep K step of a wave's 64 x 64 sub-tile
+__device__ __forceinline__ void mma_step(const unsigned char *la, const unsigned char *lb, int arow0, int brow0, int frow,
+                                         int fq, f32x4 (&acc)[4][4]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int kk = 0; kk < 2; kk++) {
+        bf16x8 af[4], bfr[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = g.K / BK;
-    stage_tile(g.A, g.lda, m0, g.M, 0, lds, wave, lane);
-    stage_tile(g.W, g.ldw, n0, g.N, 0, lds + TILE_BYTES, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const int frow = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        unsigned char *la = lds + cur * 2 * TILE_BYTES;
-        unsigned char *lb = la + TILE_BYTES;
-        if (kt + 1 < nk) {
-            unsigned char *na = lds + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile(g.A, g.lda, m0, g.M, (kt + 1) * BK, na, wave, lane);
-            stage_tile(g.W, g.ldw, n0, g.N, (kt + 1) * BK, na + TILE_BYTES, wave, lane);
-        }
+        for (int i = 0; i < 4; i++) af[i] = *(const bf16x8 *)(la + lds_off(arow0 + i * 16 + frow, kk * 4 + fq));
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            bf16x8 af[4], bfr[4];
+        for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(lb + lds_off(brow0 + j * 16 + frow, kk * 4 + fq));
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int row = wm * 64 + i * 16 + frow;
-                af[i] = *(const bf16x8 *)(la + lds_off(row, kk * 4 + fq));
-            }
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int row = wn * 64 + j * 16 + frow;
-                bfr[j] = *(const bf16x8 *)(lb + lds_off(row, kk * 4 + fq));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+            for (int j = 0; j < 4; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
+}
 
-    // epilogue: acc[i][j][e] is C[m0 + wm*64 + i*16 + fq*4 + e][n0 + wn*64 + j*16 + frow]
+// acc[i][j][e] is C[mw + i*16 + fq*4 + e][nw + j*16 + frow]
+template <int EPI>
+__device__ __forceinline__ void epilogue(const GemmArgs &g, const f32x4 (&acc)[4][4], int mw, int nw, int frow, int fq) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int n = n0 + wn * 64 + j * 16 + frow;
+        const int n = nw + j * 16 + frow;
         if (n >= g.N) continue;
         float bias = 0.f;
         if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16 || EPI == SGCLIP_EPI_BIAS_RESID_F32)
@@ -126,9 +93,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
         for (int i = 0; i < 4; i++) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const int m = m0 + wm * 64 + i * 16 + fq * 4 + e;
+                const int m = mw + i * 16 + fq * 4 + e;
                 if (m >= g.M) continue;
-                float v = acc[i][j][e] + bias;
+                const float v = acc[i][j][e] + bias;
                 if (EPI == SGCLIP_EPI_BIAS_BF16) {
                     ((bf16_t *)g.C)[(size_t)m * g.ldc + n] = (bf16_t)v;
                 } else if (EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
@@ -146,6 +113,355 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmArgs g) {
                 }
             }
         }
+    }
+}
+
+// Coalesced epilogue: the wave parks its 64 x 64 fp32 sub-tile in a private LDS
+// region (row stride 68 floats: the two row groups of a 32-lane half land 16 banks
+// apart) and reads it back row-contiguous, so every global access is a float4 (or
+// 4 x bf16) per lane and 256 (128) contiguous bytes per row.
+constexpr int EPI_LD = 68;
+constexpr int EPI_WAVE_BYTES = 64 * EPI_LD * 4;  // 17 408
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs &g, const f32x4 (&acc)[4][4], float *region, int mw, int nw,
+                                             int lane) {
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) region[(i * 16 + fq * 4 + e) * EPI_LD + j * 16 + frow] = acc[i][j][e];
+    __syncthreads();
+    const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+    const int n = nw + c4;
+    if (n >= g.N) return;  // N is a multiple of 4 wherever this epilogue is used
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16 || EPI == SGCLIP_EPI_BIAS_RESID_F32)
+        bias = *(const float4 *)(g.bias + n);
+#pragma unroll 4
+    for (int rr = 0; rr < 16; rr++) {
+        const int row = rr * 4 + r0;
+        const int m = mw + row;
+        if (m >= g.M) continue;
+        float4 v = *(const float4 *)(region + row * EPI_LD + c4);
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
+            if (EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
+                v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+            }
+            bf16x4 o;
+            o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+            *(bf16x4 *)((bf16_t *)g.C + (size_t)m * g.ldc + n) = o;
+        } else if (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
+            float4 *p = (float4 *)((float *)g.C + (size_t)m * g.ldc + n);
+            const float4 c = *p;
+            *p = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
+        } else if (EPI == SGCLIP_EPI_PATCH_F32) {
+            const int P = g.aux_rows;
+            const int img = m / P, pp = m - img * P;
+            const size_t orow = (size_t)img * (P + 1) + 1 + pp;
+            const float4 a = *(const float4 *)(g.aux + (size_t)(1 + pp) * g.ldc + n);
+            *(float4 *)((float *)g.C + orow * g.ldc + n) = make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+        } else {
+            *(float4 *)((float *)g.C + (size_t)m * g.ldc + n) = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 128 x 128 tile, 4 waves, 2 LDS slots (small problems)
+// ---------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    constexpr int TILE = 128 * 128;  // bytes per operand tile
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * TILE];  // A0 B0 A1 B1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = swz / g.tiles_n, tn = swz - tm * g.tiles_n;
+    const int m0 = tm * 128, n0 = tn * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int kt, unsigned char *slot) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) stage_piece(g.A, g.lda, m0, g.M, kt * BK, slot, wave * 4 + i, lane);
+#pragma unroll
+        for (int i = 0; i < 4; i++) stage_piece(g.W, g.ldw, n0, g.N, kt * BK, slot + TILE, wave * 4 + i, lane);
+    };
+    const int nk = g.K / BK;
+    stage(0, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int frow = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; kt++) {
+        unsigned char *la = lds + (kt & 1) * 2 * TILE;
+        if (kt + 1 < nk) stage(kt + 1, lds + ((kt + 1) & 1) * 2 * TILE);
+        mma_step(la, la + TILE, wm * 64, wn * 64, frow, fq, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    epilogue<EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, frow, fq);
+}
+
+// ---------------------------------------------------------------------------
+// 256 x 128 tile, 8 waves (4 x 2), 3-slot LDS ring, counted vmcnt across a raw barrier
+// ---------------------------------------------------------------------------
+constexpr int RING_BM = 256;
+constexpr int RING_A = RING_BM * 128, RING_B = BN * 128, RING_SLOT = RING_A + RING_B;  // 48 KiB
+constexpr int RING_SLOTS = 3;
+constexpr int RING_PW = (RING_SLOT / 1024) / 8;  // DMA instructions per wave per tile = 6
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = swz / g.tiles_n, tn = swz - tm * g.tiles_n;
+    const int m0 = tm * RING_BM, n0 = tn * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // 48 pieces per tile: piece = wave + 8 i; i < 4 -> A (32 pieces), i = 4, 5 -> W (16 pieces)
+    auto stage = [&](int kt, unsigned char *slot) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) stage_piece(g.A, g.lda, m0, g.M, kt * BK, slot, wave + 8 * i, lane);
+#pragma unroll
+        for (int i = 0; i < 2; i++) stage_piece(g.W, g.ldw, n0, g.N, kt * BK, slot + RING_A, wave + 8 * i, lane);
+    };
+    const int nk = g.K / BK;
+    stage(0, lds);
+    if (nk > 1) stage(1, lds + RING_SLOT);
+    const int frow = lane & 15, fq = lane >> 4;
+    int slot = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        // tile kt has landed once at most the DMAs of tile kt+1 are outstanding
+        if (kt + 1 < nk)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING_PW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // tile kt visible to all waves; slot of tile kt-1 is free
+        asm volatile("" ::: "memory");  // keep this iteration's LDS reads and DMA issue below the barrier
+        if (kt + 2 < nk) {
+            int ns = slot + 2;
+            ns = ns >= RING_SLOTS ? ns - RING_SLOTS : ns;
+            stage(kt + 2, lds + ns * RING_SLOT);
+        }
+        const unsigned char *la = lds + slot * RING_SLOT;
+        __builtin_amdgcn_s_setprio(1);
+        mma_step(la, la + RING_A, wm * 64, wn * 64, frow, fq, acc);
+        __builtin_amdgcn_s_setprio(0);
+        slot = slot + 1 == RING_SLOTS ? 0 : slot + 1;
+    }
+    if (g.wide_epilogue) {
+        __syncthreads();  // every wave has finished reading the last tile: the ring becomes epilogue space
+        epilogue_lds<EPI>(g, acc, (float *)(lds + wave * EPI_WAVE_BYTES), m0 + wm * 64, n0 + wn * 64, lane);
+    } else {
+        epilogue<EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, frow, fq);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 256 x 128 tile, 8 waves, K step 32, 3-slot ring of 24 KiB: two workgroups per CU, so
+// one workgroup's epilogue (LDS round trip + global stores) runs under the other's MFMAs.
+//
+// LDS image of a 32-deep operand tile: 128-byte LDS row i holds tile row i (64 B) followed
+// by tile row i + RH (RH = half the tile's rows); the 16-byte chunk positions of an LDS row
+// are XOR-swizzled with bits 1..3 of i, which keeps the ds_read_b128 fragment reads
+// conflict free exactly as in the 64-deep image.
+// ---------------------------------------------------------------------------
+constexpr int R32_A = 256 * 64, R32_B = BN * 64, R32_SLOT = R32_A + R32_B;  // 24 KiB
+constexpr int R32_SLOTS = 3;
+constexpr int R32_PW = (R32_SLOT / 1024) / 8;  // 3 DMA instructions per wave per tile
+
+template <int RH>
+__device__ __forceinline__ void stage_piece32(const bf16_t *__restrict__ G, int ld, int row0, int max_row, int k0,
+                                              unsigned char *lds_tile, int piece, int lane) {
+    const int lrow = piece * 8 + (lane >> 3);
+    const int pos = (lane & 7) ^ ((lrow >> 1) & 7);  // logical position held by this lane's LDS chunk
+    int grow = row0 + lrow + (pos >> 2) * RH;
+    grow = grow < max_row ? grow : max_row - 1;
+    const bf16_t *src = G + (size_t)grow * ld + k0 + (pos & 3) * 8;
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
+}
+
+template <int RH>
+__device__ __forceinline__ int lds_off32(int row, int c) {
+    const int lrow = row & (RH - 1);
+    const int pos = c + 4 * (row / RH);
+    return lrow * 128 + ((pos ^ ((lrow >> 1) & 7)) << 4);
+}
+
+// 16-row passes of the coalesced epilogue (4 352 B of LDS per wave)
+constexpr int EPI_PASS_BYTES = 16 * EPI_LD * 4;
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (&acc)[4][4], float *region, int mw, int nw,
+                                                int lane) {
+    const int frow = lane & 15, fq = lane >> 4;
+    const int c4 = (lane & 15) * 4, r0 = lane >> 4;
+    const int n = nw + c4;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16 || EPI == SGCLIP_EPI_BIAS_RESID_F32)
+        if (n < g.N) bias = *(const float4 *)(g.bias + n);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) region[(fq * 4 + e) * EPI_LD + j * 16 + frow] = acc[i][j][e];
+        // the region is private to this wave: order the LDS writes before the reads of other lanes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int row = rr * 4 + r0;
+            const int m = mw + i * 16 + row;
+            float4 v = *(const float4 *)(region + row * EPI_LD + c4);
+            if (m >= g.M || n >= g.N) continue;
+            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+            if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
+                if (EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
+                    v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+                }
+                bf16x4 o;
+                o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+                *(bf16x4 *)((bf16_t *)g.C + (size_t)m * g.ldc + n) = o;
+            } else if (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
+                float4 *p = (float4 *)((float *)g.C + (size_t)m * g.ldc + n);
+                const float4 c = *p;
+                *p = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
+            } else if (EPI == SGCLIP_EPI_PATCH_F32) {
+                const int P = g.aux_rows;
+                const int img = m / P, pp = m - img * P;
+                const size_t orow = (size_t)img * (P + 1) + 1 + pp;
+                const float4 a = *(const float4 *)(g.aux + (size_t)(1 + pp) * g.ldc + n);
+                *(float4 *)((float *)g.C + orow * g.ldc + n) = make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+            } else {
+                *(float4 *)((float *)g.C + (size_t)m * g.ldc + n) = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void gemm_ring32_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = swz / g.tiles_n, tn = swz - tm * g.tiles_n;
+    const int m0 = tm * RING_BM, n0 = tn * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // 24 pieces per tile: piece = wave + 8 i; i = 0, 1 -> A (16 pieces), i = 2 -> W (8 pieces)
+    auto stage = [&](int kt, unsigned char *slot) {
+        stage_piece32<128>(g.A, g.lda, m0, g.M, kt * 32, slot, wave, lane);
+        stage_piece32<128>(g.A, g.lda, m0, g.M, kt * 32, slot, wave + 8, lane);
+        stage_piece32<64>(g.W, g.ldw, n0, g.N, kt * 32, slot + R32_A, wave, lane);
+    };
+    const int nk = g.K / 32;
+    stage(0, lds);
+    if (nk > 1) stage(1, lds + R32_SLOT);
+    const int frow = lane & 15, fq = lane >> 4;
+    int slot = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        if (kt + 1 < nk)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R32_PW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) {
+            int ns = slot + 2;
+            ns = ns >= R32_SLOTS ? ns - R32_SLOTS : ns;
+            stage(kt + 2, lds + ns * R32_SLOT);
+        }
+        const unsigned char *la = lds + slot * R32_SLOT;
+        const unsigned char *lb = la + R32_A;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) af[i] = *(const bf16x8 *)(la + lds_off32<128>(wm * 64 + i * 16 + frow, fq));
+#pragma unroll
+        for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(lb + lds_off32<64>(wn * 64 + j * 16 + frow, fq));
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        slot = slot + 1 == R32_SLOTS ? 0 : slot + 1;
+    }
+    if (g.wide_epilogue) {
+        __syncthreads();
+        epilogue_passes<EPI>(g, acc, (float *)(lds + wave * EPI_PASS_BYTES), m0 + wm * 64, n0 + wn * 64, lane);
+    } else {
+        epilogue<EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, frow, fq);
+    }
+}
+
+static int gemm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SGCLIP_GEMM_VARIANT");
+        v = e ? atoi(e) : 3;
+    }
+    return v;
+}
+
+template <int EPI>
+static void launch(const GemmArgs &g0, hipStream_t stream) {
+    GemmArgs g = g0;
+    // measured on MI355X (M = 65536, random data): the 32-deep two-workgroups-per-CU kernel wins
+    // for short K (epilogue-heavy), the 64-deep ring for long K
+    const int variant = gemm_variant();
+    const bool use32 = variant == 2 || (variant == 3 && g.K <= 1024);
+    if (use32 && g.M > 128 && g.K % 32 == 0) {
+        g.tiles_m = ceil_div(g.M, RING_BM);
+        static bool attr_set32 = false;
+        if (!attr_set32) {
+            (void)hipFuncSetAttribute((const void *)gemm_ring32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      R32_SLOTS * R32_SLOT);
+            attr_set32 = true;
+        }
+        hipLaunchKernelGGL(gemm_ring32_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n), dim3(512), R32_SLOTS * R32_SLOT,
+                           stream, g);
+    } else if (gemm_variant() >= 1 && g.M > 128) {
+        g.tiles_m = ceil_div(g.M, RING_BM);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      RING_SLOTS * RING_SLOT);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemm_ring_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n), dim3(512), RING_SLOTS * RING_SLOT,
+                           stream, g);
+    } else {
+        g.tiles_m = ceil_div(g.M, 128);
+        hipLaunchKernelGGL(gemm_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n), dim3(256), 0, stream, g);
     }
 }
 
@@ -186,16 +502,17 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
     g.N = N;
     g.K = K;
     g.aux_rows = aux_rows;
-    g.tiles_m = ceil_div(M, BM);
+    g.tiles_m = 0;
     g.tiles_n = ceil_div(N, BN);
-    const dim3 grid((unsigned)g.tiles_m * g.tiles_n), block(GEMM_THREADS);
+    g.wide_epilogue = (N % 4 == 0) && (ldc % 4 == 0) && !((uintptr_t)C_dev & 15) && !((uintptr_t)bias_dev & 15) &&
+                      !((uintptr_t)aux_dev & 15);
     KernelTimer timer(TK_GEMM0 + epilogue, 2.0 * M * N * K, stream);
     switch (epilogue) {
-        case SGCLIP_EPI_BIAS_BF16: hipLaunchKernelGGL(gemm_kernel<SGCLIP_EPI_BIAS_BF16>, grid, block, 0, stream, g); break;
-        case SGCLIP_EPI_BIAS_GELU_BF16: hipLaunchKernelGGL(gemm_kernel<SGCLIP_EPI_BIAS_GELU_BF16>, grid, block, 0, stream, g); break;
-        case SGCLIP_EPI_BIAS_RESID_F32: hipLaunchKernelGGL(gemm_kernel<SGCLIP_EPI_BIAS_RESID_F32>, grid, block, 0, stream, g); break;
-        case SGCLIP_EPI_PATCH_F32: hipLaunchKernelGGL(gemm_kernel<SGCLIP_EPI_PATCH_F32>, grid, block, 0, stream, g); break;
-        case SGCLIP_EPI_F32: hipLaunchKernelGGL(gemm_kernel<SGCLIP_EPI_F32>, grid, block, 0, stream, g); break;
+        case SGCLIP_EPI_BIAS_BF16: launch<SGCLIP_EPI_BIAS_BF16>(g, stream); break;
+        case SGCLIP_EPI_BIAS_GELU_BF16: launch<SGCLIP_EPI_BIAS_GELU_BF16>(g, stream); break;
+        case SGCLIP_EPI_BIAS_RESID_F32: launch<SGCLIP_EPI_BIAS_RESID_F32>(g, stream); break;
+        case SGCLIP_EPI_PATCH_F32: launch<SGCLIP_EPI_PATCH_F32>(g, stream); break;
+        case SGCLIP_EPI_F32: launch<SGCLIP_EPI_F32>(g, stream); break;
         default: set_error("sgclip_gemm_bf16: unknown epilogue %d", epilogue); return SGCLIP_EINVAL;
     }
     return launch_check("sgclip_gemm_bf16");
