@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--objects", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=240)
+    ap.add_argument("--forward-api", action="store_true",
+                    help="also time PredicateModel.forward() from host numpy inputs (PCIe + host index build included)")
     return ap.parse_args()
 
 
@@ -258,6 +260,26 @@ def main():
         "kernel_ms_per_step": step_ms_timed,
         "whole_step_tflops": encodes_per_step * cfg.vit_flops_per_encode() / (ms_per_step * 1e-3) / 1e12,
     }
+    if args.forward_api and world == 1:
+        kw = batch.forward_kwargs()
+        model(**kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            model(**kw)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        staged = model.stage_inputs(batch.batched_videos, batch.batched_masks)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            model(**kw, device_inputs=staged)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / 2
+        result["forward_api"] = {"host_inputs_ms": dt * 1e3, "host_inputs_crops_per_s": crops_per_step / dt,
+                                 "staged_inputs_ms": dt2 * 1e3, "staged_inputs_crops_per_s": crops_per_step / dt2,
+                                 "note": "PredicateModel.forward(): host index build + lazy mappings; host_inputs also "
+                                         "concatenates and uploads frames and masks over PCIe; text features cached (eval)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         result["cpu_baseline"] = cpu_baseline(args, cfg, sd, tok, batch)
