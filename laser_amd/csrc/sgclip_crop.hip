@@ -145,7 +145,18 @@ struct CropArgs {
     void *out;
     int S, nbands, layout, patch, kpad, out_dtype;
     int ksx_cap, ksy_cap, wn_cap;
+    int need_lo, need_hi;  // this launch handles the crops whose own LDS need is in (need_lo, need_hi]
 };
+
+// LDS bytes one crop needs when staged with exactly its own tap counts and source span
+__host__ __device__ inline int crop_need(int w, int h, int S) {
+    int new_w, new_h, top, left;
+    crop_geom(w, h, S, new_w, new_h, top, left);
+    int x0, n0, x1, n1;
+    axis_bounds(w, new_w, left, x0, n0);
+    axis_bounds(w, new_w, left + S - 1, x1, n1);
+    return crop_lds(S, axis_ksize(w, new_w), axis_ksize(h, new_h), x1 + n1 - x0).total;
+}
 
 __device__ __forceinline__ int clip8(int v) {
     v >>= PREC;
@@ -162,6 +173,10 @@ __global__ __launch_bounds__(NT) void crop_kernel(CropArgs a) {
     const sgclip_crop_t c = a.crops[crop_i];
     const int S = a.S;
     const int w = c.x2 - c.x1, h = c.y2 - c.y1;
+    {   // crops are binned by LDS need so that small crops run at high occupancy
+        const int need = crop_need(w, h, S);
+        if (need <= a.need_lo || need > a.need_hi) return;
+    }
     int new_w, new_h, top, left;
     crop_geom(w, h, S, new_w, new_h, top, left);
 
@@ -390,7 +405,9 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
         set_error("sgclip_crop_preprocess: frames_dev / masks_dev must be 4-byte aligned");
         return SGCLIP_EINVAL;
     }
-    int ksx = 1, ksy = 1, wn_cap = 1;
+    // occupancy classes by LDS need: 4 / 3 / 2 / 1 workgroups per CU
+    static const int class_hi[4] = {40 * 1024, 53 * 1024, 80 * 1024, LDS_LIMIT};
+    int ksx[4] = {1, 1, 1, 1}, ksy[4] = {1, 1, 1, 1}, wnc[4] = {1, 1, 1, 1}, members[4] = {0, 0, 0, 0};
     double algo_bytes = 0;  // per crop: 3hw frame + m*hw mask + out
     for (int i = 0; i < n_crops; i++) {
         const sgclip_crop_t &c = crops[i];
@@ -419,18 +436,21 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
                       3.0 * S * S * (out_dtype == SGCLIP_DTYPE_BF16 ? 2 : 4);
         int new_w, new_h, top, left;
         crop_geom(w, h, S, new_w, new_h, top, left);
-        ksx = std::max(ksx, axis_ksize(w, new_w));
-        ksy = std::max(ksy, axis_ksize(h, new_h));
         int x0, n0, x1, n1;
         axis_bounds(w, new_w, left, x0, n0);
         axis_bounds(w, new_w, left + S - 1, x1, n1);
-        wn_cap = std::max(wn_cap, x1 + n1 - x0);
-    }
-    const CropLds L = crop_lds(S, ksx, ksy, wn_cap);
-    if (L.total > LDS_LIMIT) {
-        set_error("sgclip_crop_preprocess: a crop needs %d bytes of LDS staging (limit %d): source span %d px, %d taps",
-                  L.total, LDS_LIMIT, wn_cap, ksx);
-        return SGCLIP_EINVAL;
+        const int need = crop_need(w, h, S);
+        if (need > LDS_LIMIT) {
+            set_error("sgclip_crop_preprocess: crop %d needs %d bytes of LDS staging (limit %d): source span %d px", i, need,
+                      LDS_LIMIT, x1 + n1 - x0);
+            return SGCLIP_EINVAL;
+        }
+        int k = 0;
+        while (need > class_hi[k]) k++;
+        ksx[k] = std::max(ksx[k], axis_ksize(w, new_w));
+        ksy[k] = std::max(ksy[k], axis_ksize(h, new_h));
+        wnc[k] = std::max(wnc[k], x1 + n1 - x0);
+        members[k]++;
     }
     uint8_t *lut8_dev = (uint8_t *)lut_dev;
     float *norm_dev = (float *)(lut8_dev + 768);
@@ -455,17 +475,28 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
     a.patch = patch;
     a.kpad = kpad;
     a.out_dtype = out_dtype;
-    a.ksx_cap = ksx;
-    a.ksy_cap = ksy;
-    a.wn_cap = wn_cap;
     const dim3 grid((unsigned)n_crops * a.nbands), block(NT);
     KernelTimer timer(TK_CROP, algo_bytes, stream);
-    if (S <= NT) {
-        (void)hipFuncSetAttribute((const void *)crop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-        hipLaunchKernelGGL(crop_kernel<1>, grid, block, L.total, stream, a);
-    } else {
-        (void)hipFuncSetAttribute((const void *)crop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
-        hipLaunchKernelGGL(crop_kernel<2>, grid, block, L.total, stream, a);
+    for (int k = 0; k < 4; k++) {
+        if (!members[k]) continue;
+        a.ksx_cap = ksx[k];
+        a.ksy_cap = ksy[k];
+        a.wn_cap = wnc[k];
+        a.need_lo = k ? class_hi[k - 1] : 0;
+        a.need_hi = class_hi[k];
+        // a class's shared capacities can exceed its bound (taps from one crop, span from another)
+        const int lds_bytes = crop_lds(S, ksx[k], ksy[k], wnc[k]).total;
+        if (lds_bytes > LDS_LIMIT) {
+            set_error("sgclip_crop_preprocess: LDS class %d needs %d bytes", k, lds_bytes);
+            return SGCLIP_EINVAL;
+        }
+        if (S <= NT) {
+            (void)hipFuncSetAttribute((const void *)crop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+            hipLaunchKernelGGL(crop_kernel<1>, grid, block, lds_bytes, stream, a);
+        } else {
+            (void)hipFuncSetAttribute((const void *)crop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+            hipLaunchKernelGGL(crop_kernel<2>, grid, block, lds_bytes, stream, a);
+        }
     }
     return launch_check("sgclip_crop_preprocess");
 }

@@ -35,7 +35,8 @@ struct GemmArgs {
     int M, N, K;
     int aux_rows;
     int tiles_m, tiles_n;
-    int wide_epilogue;  // N % 4 == 0, ldc % 4 == 0 and C, bias, aux 16-byte aligned
+    int wide_epilogue;  // N % 8 == 0, ldc % 8 == 0 and C, bias, aux 16-byte aligned
+    int debug_mode;     // diagnostics only: 1 = skip epilogue stores, 2 = single K step
 };
 
 // byte offset of 16-byte chunk `c` (0..7) of tile row `row` in the swizzled LDS image
@@ -52,7 +53,10 @@ __device__ __forceinline__ void stage_piece(const bf16_t *__restrict__ G, int ld
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
 }
 
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// x * sigmoid(1.702 x) with the hardware exp2 / rcp (relative error ~1e-6, far below bf16 output rounding)
+__device__ __forceinline__ float quick_gelu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x));
+}
 
 // XCD-aware remap: blocks that share an XCD (same blockIdx % 8) walk neighbouring
 // tiles of one A row panel, so the panel stays in that XCD's L2.  Bijective for any grid.
@@ -307,17 +311,26 @@ __device__ __forceinline__ int lds_off32(int row, int c) {
 // 16-row passes of the coalesced epilogue (4 352 B of LDS per wave)
 constexpr int EPI_PASS_BYTES = 16 * EPI_LD * 4;
 
-template <int EPI>
-__device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (&acc)[4][4], float *region, int mw, int nw,
+template <int EPI, int NI>
+__device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (&acc)[NI][4], float *region, int mw, int nw,
                                                 int lane) {
     const int frow = lane & 15, fq = lane >> 4;
     const int c4 = (lane & 15) * 4, r0 = lane >> 4;
     const int n = nw + c4;
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16 || EPI == SGCLIP_EPI_BIAS_RESID_F32)
+    if (EPI == SGCLIP_EPI_BIAS_RESID_F32)
         if (n < g.N) bias = *(const float4 *)(g.bias + n);
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
+        const int n8 = nw + (lane & 7) * 8;
+        if (n8 < g.N) {   // the wide epilogue is only used when N % 8 == 0
+            const float4 b0 = *(const float4 *)(g.bias + n8), b1 = *(const float4 *)(g.bias + n8 + 4);
+            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+            bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        }
+    }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NI; i++) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -326,6 +339,24 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
+            // bf16 rows: 8 columns (16 bytes) per lane, 8 rows per store instruction
+            const int c8 = (lane & 7) * 8, n8 = nw + c8;
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int row = rr * 8 + (lane >> 3);
+                const int m = mw + i * 16 + row;
+                const float4 v0 = *(const float4 *)(region + row * EPI_LD + c8);
+                const float4 v1 = *(const float4 *)(region + row * EPI_LD + c8 + 4);
+                if (m >= g.M || n8 >= g.N) continue;
+                float v[8] = {v0.x + bias8[0], v0.y + bias8[1], v0.z + bias8[2], v0.w + bias8[3],
+                              v1.x + bias8[4], v1.y + bias8[5], v1.z + bias8[6], v1.w + bias8[7]};
+                bf16x8 o;
+#pragma unroll
+                for (int q = 0; q < 8; q++) o[q] = (bf16_t)(EPI == SGCLIP_EPI_BIAS_GELU_BF16 ? quick_gelu(v[q]) : v[q]);
+                *(bf16x8 *)((bf16_t *)g.C + (size_t)m * g.ldc + n8) = o;
+            }
+        } else {
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
             const int row = rr * 4 + r0;
@@ -333,14 +364,7 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
             float4 v = *(const float4 *)(region + row * EPI_LD + c4);
             if (m >= g.M || n >= g.N) continue;
             v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-            if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
-                if (EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
-                    v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
-                }
-                bf16x4 o;
-                o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
-                *(bf16x4 *)((bf16_t *)g.C + (size_t)m * g.ldc + n) = o;
-            } else if (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
+            if (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
                 float4 *p = (float4 *)((float *)g.C + (size_t)m * g.ldc + n);
                 const float4 c = *p;
                 *p = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
@@ -353,6 +377,7 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
             } else {
                 *(float4 *)((float *)g.C + (size_t)m * g.ldc + n) = v;
             }
+        }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -417,9 +442,98 @@ __global__ __launch_bounds__(512, 4) void gemm_ring32_kernel(GemmArgs g) {
     }
     if (g.wide_epilogue) {
         __syncthreads();
-        epilogue_passes<EPI>(g, acc, (float *)(lds + wave * EPI_PASS_BYTES), m0 + wm * 64, n0 + wn * 64, lane);
+        epilogue_passes<EPI, 4>(g, acc, (float *)(lds + wave * EPI_PASS_BYTES), m0 + wm * 64, n0 + wn * 64, lane);
     } else {
         epilogue<EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, frow, fq);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 256 x 256 tile, 8 waves (2 x 4) of 128 x 64, K step 32, 4-slot ring of 32 KiB.
+// The larger wave tile needs 12 fragment reads per 32 MFMAs (the 64 x 64 tile: 8 per 16) and
+// the larger block tile halves the DMA bytes per MFMA, which takes the LDS off the critical
+// path; used when the grid still fills the chip.
+// ---------------------------------------------------------------------------
+constexpr int BIG_A = 256 * 64, BIG_SLOT = 2 * BIG_A;  // 32 KiB
+constexpr int BIG_SLOTS = 4;
+constexpr int BIG_PW = (BIG_SLOT / 1024) / 8;  // 4 DMA instructions per wave per tile
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = swz / g.tiles_n, tn = swz - tm * g.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // 32 pieces per tile: piece = wave + 8 i; i = 0, 1 -> A, i = 2, 3 -> W
+    auto stage = [&](int kt, unsigned char *slot) {
+        stage_piece32<128>(g.A, g.lda, m0, g.M, kt * 32, slot, wave, lane);
+        stage_piece32<128>(g.A, g.lda, m0, g.M, kt * 32, slot, wave + 8, lane);
+        stage_piece32<128>(g.W, g.ldw, n0, g.N, kt * 32, slot + BIG_A, wave, lane);
+        stage_piece32<128>(g.W, g.ldw, n0, g.N, kt * 32, slot + BIG_A, wave + 8, lane);
+    };
+    const int nk = g.debug_mode == 2 ? 1 : g.K / 32;
+    stage(0, lds);
+    if (nk > 1) stage(1, lds + BIG_SLOT);
+    if (nk > 2) stage(2, lds + 2 * BIG_SLOT);
+    const int frow = lane & 15, fq = lane >> 4;
+    int slot = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        // tile kt has landed once at most the DMAs of tiles kt+1 and kt+2 are outstanding
+        if (kt + 2 < nk)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * BIG_PW) : "memory");
+        else if (kt + 1 < nk)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BIG_PW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 3 < nk) stage(kt + 3, lds + ((slot + 3) & 3) * BIG_SLOT);
+        const unsigned char *la = lds + slot * BIG_SLOT;
+        const unsigned char *lb = la + BIG_A;
+        bf16x8 af[8], bfr[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(lb + lds_off32<128>(wn * 64 + j * 16 + frow, fq));
+#pragma unroll
+        for (int i = 0; i < 8; i++) af[i] = *(const bf16x8 *)(la + lds_off32<128>(wm * 128 + i * 16 + frow, fq));
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        slot = (slot + 1) & 3;
+    }
+    if (g.debug_mode == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    if (g.wide_epilogue) {
+        __syncthreads();
+        epilogue_passes<EPI, 8>(g, acc, (float *)(lds + wave * EPI_PASS_BYTES), m0 + wm * 128, n0 + wn * 64, lane);
+    } else {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            f32x4 part[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) part[i][j] = acc[half * 4 + i][j];
+            epilogue<EPI>(g, part, m0 + wm * 128 + half * 64, n0 + wn * 64, frow, fq);
+        }
     }
 }
 
@@ -427,7 +541,7 @@ static int gemm_variant() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("SGCLIP_GEMM_VARIANT");
-        v = e ? atoi(e) : 3;
+        v = e ? atoi(e) : 5;
     }
     return v;
 }
@@ -438,8 +552,20 @@ static void launch(const GemmArgs &g0, hipStream_t stream) {
     // measured on MI355X (M = 65536, random data): the 32-deep two-workgroups-per-CU kernel wins
     // for short K (epilogue-heavy), the 64-deep ring for long K
     const int variant = gemm_variant();
-    const bool use32 = variant == 2 || (variant == 3 && g.K <= 1024);
-    if (use32 && g.M > 128 && g.K % 32 == 0) {
+    const bool use32 = variant == 2 || (variant >= 3 && g.K <= 1024);
+    const long big_tiles = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256);
+    if ((variant == 4 || (variant == 5 && big_tiles >= 512)) && g.M > 128 && g.K % 32 == 0 && g.N >= 256) {
+        g.tiles_m = ceil_div(g.M, 256);
+        g.tiles_n = ceil_div(g.N, 256);
+        static bool attr_big = false;
+        if (!attr_big) {
+            (void)hipFuncSetAttribute((const void *)gemm_big_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      BIG_SLOTS * BIG_SLOT);
+            attr_big = true;
+        }
+        hipLaunchKernelGGL(gemm_big_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n), dim3(512), BIG_SLOTS * BIG_SLOT,
+                           stream, g);
+    } else if (use32 && g.M > 128 && g.K % 32 == 0) {
         g.tiles_m = ceil_div(g.M, RING_BM);
         static bool attr_set32 = false;
         if (!attr_set32) {
@@ -504,7 +630,15 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
     g.aux_rows = aux_rows;
     g.tiles_m = 0;
     g.tiles_n = ceil_div(N, BN);
-    g.wide_epilogue = (N % 4 == 0) && (ldc % 4 == 0) && !((uintptr_t)C_dev & 15) && !((uintptr_t)bias_dev & 15) &&
+    {
+        static int dbg = -1;
+        if (dbg < 0) {
+            const char *e = getenv("SGCLIP_GEMM_DEBUG");
+            dbg = e ? atoi(e) : 0;
+        }
+        g.debug_mode = dbg;
+    }
+    g.wide_epilogue = (N % 8 == 0) && (ldc % 8 == 0) && !((uintptr_t)C_dev & 15) && !((uintptr_t)bias_dev & 15) &&
                       !((uintptr_t)aux_dev & 15);
     KernelTimer timer(TK_GEMM0 + epilogue, 2.0 * M * N * K, stream);
     switch (epilogue) {
