@@ -109,7 +109,7 @@ static int vit_chunk() {
     if (!v) {
         const char *e = getenv("SGCLIP_VIT_CHUNK_ROWS");
         v = e ? atoi(e) : 0;
-        if (v <= 0) v = 65536;
+        if (v <= 0) v = 262144;
     }
     return v;
 }

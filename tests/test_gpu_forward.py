@@ -93,3 +93,36 @@ def test_top1_agreement_b32():
     assert worst <= PROB_TOL, worst
     assert agree / total >= 0.99, (agree, total)
     print(f"b32: max |p - oracle| = {worst:.3e}, top-1 agreement {agree}/{total}")
+
+
+def test_vit_l14_336_towers_match_oracle():
+    """ViT-L/14@336 geometry (T = 577, d = 1024, patch K padded 588 -> 640, text d = 768):
+    image and text features of the HIP towers against the fp32 oracle."""
+    from laser_amd import _lib, ops
+    from laser_amd.weights import random_state_dict
+    from oracle import clip_ref, resample_ref
+    cfg = config_by_name("vit-l-14-336")
+    sd = random_state_dict(cfg, 17)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4)
+    H, W = 200, 300
+    frame = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+    boxes = [(0, 0, W, H), (20, 30, 180, 170), (100, 10, 290, 60)]
+    rows = [(0, -1, -1, W, H, x1, y1, x2, y2, _lib.CROP_PLAIN, 0) for (x1, y1, x2, y2) in boxes]
+    from laser_amd.predicate_model import CROP_DTYPE
+    frames_t = torch.from_numpy(ops.pad_bytes(frame)).to(dev)
+    patches = ops.crop_preprocess(frames_t, None, np.array(rows, dtype=CROP_DTYPE), 336, layout=_lib.LAYOUT_PATCHES,
+                                  patch=14, out_dtype=_lib.DTYPE_BF16)
+    got = ops.Tower(cfg, "vision", sd, dev).encode_images(patches, len(boxes)).cpu()
+    px = torch.from_numpy(np.stack([resample_ref.preprocess(frame[y1:y2, x1:x2], 336) for (x1, y1, x2, y2) in boxes]))
+    torch.set_num_threads(16)
+    want = clip_ref.image_features(sd, cfg, px)
+    rel = ((got - want).norm(dim=-1) / want.norm(dim=-1)).max().item()
+    assert rel < 1e-2, rel
+    tok = HashTokenizer(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    t = tok(["a person riding a horse", "dog", "the quick brown fox jumps over the lazy dog " * 12])
+    tgot = ops.Tower(cfg, "text", sd, dev).encode_text(t["input_ids"], t["attention_mask"]).cpu()
+    twant = clip_ref.text_features(sd, cfg, t["input_ids"], t["attention_mask"])
+    trel = ((tgot - twant).norm(dim=-1) / twant.norm(dim=-1)).max().item()
+    assert trel < 1e-2, trel
+    print(f"L/14-336: image feature rel err {rel:.2e}, text feature rel err {trel:.2e}")
