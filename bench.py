@@ -121,6 +121,20 @@ def score_clip(model: PredicateModel, plan: ClipPlan):
     return cate_mean, unary, binary
 
 
+def pmc_traffic(substr):
+    """Average HBM bytes per launch of the kernels whose name contains `substr`, from the
+    rocprofv3 PMC passes over this same command (profiles/r01_pmc_bench_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as gfx950
+    requires for wide streaming reads).  None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    tot = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for k, v in ks.items() if substr in k)
+    n = sum(v["launches"] for k, v in ks.items() if substr in k)
+    return tot / n if n else None
+
+
 def timing_read(kind):
     lib = _lib.load()
     ms, n, work = C.c_double(), C.c_int64(), C.c_double()
@@ -252,10 +266,12 @@ def main():
         "clip_latency_ms": ms_per_step,
         "roofline": {"kernel": "sgclip::gemm_kernel (bf16 MFMA GEMMs of the three ViT towers + text towers, all epilogues)",
                      "bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": gemm_tflops / MFMA_PEAK_TFLOPS, "traffic": None,
+                     "frac": gemm_tflops / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("gemm"),
+                     "algorithmic_flops_per_launch": g_fl / max(g_n, 1),
                      "launches_per_step": g_n / tsteps, "avg_launch_ms": g_ms / max(g_n, 1)},
         "roofline_crop": {"kernel": "sgclip::crop_kernel", "bound": "hbm", "achieved": crop_gbs, "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": crop_gbs / HBM_PEAK_GBS, "traffic": None,
+                          "unit": "GB/s", "frac": crop_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("crop_kernel"),
+                          "algorithmic_bytes_per_launch": crop_bytes / max(crop_n, 1),
                           "avg_launch_ms": crop_ms / max(crop_n, 1), "algorithmic_bytes_per_step": plan.algo_crop_bytes},
         "kernel_ms_per_step": step_ms_timed,
         "whole_step_tflops": encodes_per_step * cfg.vit_flops_per_encode() / (ms_per_step * 1e-3) / 1e12,

@@ -308,76 +308,71 @@ __device__ __forceinline__ int lds_off32(int row, int c) {
     return lrow * 128 + ((pos ^ ((lrow >> 1) & 7)) << 4);
 }
 
-// 16-row passes of the coalesced epilogue (4 352 B of LDS per wave)
-constexpr int EPI_PASS_BYTES = 16 * EPI_LD * 4;
+// 16-row passes of the coalesced epilogue: LDS bytes per wave for NJ column blocks
+constexpr int epi_pass_bytes(int nj) { return 16 * (nj * 16 + 4) * 4; }
 
-template <int EPI, int NI>
-__device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (&acc)[NI][4], float *region, int mw, int nw,
+// NJ = 16-column blocks per wave: the wave's rows are NJ*16 contiguous columns, staged 16 rows at a
+// time (row stride NJ*16 + 4 floats keeps the two row groups of a 32-lane half 16 banks apart).
+template <int EPI, int NI, int NJ>
+__device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (&acc)[NI][NJ], float *region, int mw, int nw,
                                                 int lane) {
+    constexpr int LDW = NJ * 16 + 4;
+    constexpr bool BF = EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16;
+    constexpr int CPL = BF ? 8 : 4;                // columns per lane
+    constexpr int LPR = NJ * 16 / CPL;             // lanes per row
+    constexpr int RPI = 64 / LPR;                  // rows per store instruction
     const int frow = lane & 15, fq = lane >> 4;
-    const int c4 = (lane & 15) * 4, r0 = lane >> 4;
-    const int n = nw + c4;
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EPI == SGCLIP_EPI_BIAS_RESID_F32)
-        if (n < g.N) bias = *(const float4 *)(g.bias + n);
-    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
-        const int n8 = nw + (lane & 7) * 8;
-        if (n8 < g.N) {   // the wide epilogue is only used when N % 8 == 0
-            const float4 b0 = *(const float4 *)(g.bias + n8), b1 = *(const float4 *)(g.bias + n8 + 4);
-            bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
-            bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    const int cl = (lane % LPR) * CPL, rl = lane / LPR;
+    const int n = nw + cl;
+    float bias[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; q++) bias[q] = 0.f;
+    if ((BF || EPI == SGCLIP_EPI_BIAS_RESID_F32) && n < g.N) {   // the wide epilogue needs N % 8 == 0
+#pragma unroll
+        for (int q = 0; q < CPL; q += 4) {
+            const float4 b = *(const float4 *)(g.bias + n + q);
+            bias[q] = b.x; bias[q + 1] = b.y; bias[q + 2] = b.z; bias[q + 3] = b.w;
         }
     }
 #pragma unroll
     for (int i = 0; i < NI; i++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) region[(fq * 4 + e) * EPI_LD + j * 16 + frow] = acc[i][j][e];
+            for (int e = 0; e < 4; e++) region[(fq * 4 + e) * LDW + j * 16 + frow] = acc[i][j][e];
         // the region is private to this wave: order the LDS writes before the reads of other lanes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
-            // bf16 rows: 8 columns (16 bytes) per lane, 8 rows per store instruction
-            const int c8 = (lane & 7) * 8, n8 = nw + c8;
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                const int row = rr * 8 + (lane >> 3);
-                const int m = mw + i * 16 + row;
-                const float4 v0 = *(const float4 *)(region + row * EPI_LD + c8);
-                const float4 v1 = *(const float4 *)(region + row * EPI_LD + c8 + 4);
-                if (m >= g.M || n8 >= g.N) continue;
-                float v[8] = {v0.x + bias8[0], v0.y + bias8[1], v0.z + bias8[2], v0.w + bias8[3],
-                              v1.x + bias8[4], v1.y + bias8[5], v1.z + bias8[6], v1.w + bias8[7]};
+        for (int rr = 0; rr < 16 / RPI; rr++) {
+            const int row = rr * RPI + rl;
+            const int m = mw + i * 16 + row;
+            float v[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; q += 4) {
+                const float4 t = *(const float4 *)(region + row * LDW + cl + q);
+                v[q] = t.x + bias[q]; v[q + 1] = t.y + bias[q + 1]; v[q + 2] = t.z + bias[q + 2]; v[q + 3] = t.w + bias[q + 3];
+            }
+            if (m >= g.M || n >= g.N) continue;
+            if constexpr (BF) {
                 bf16x8 o;
 #pragma unroll
                 for (int q = 0; q < 8; q++) o[q] = (bf16_t)(EPI == SGCLIP_EPI_BIAS_GELU_BF16 ? quick_gelu(v[q]) : v[q]);
-                *(bf16x8 *)((bf16_t *)g.C + (size_t)m * g.ldc + n8) = o;
-            }
-        } else {
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const int row = rr * 4 + r0;
-            const int m = mw + i * 16 + row;
-            float4 v = *(const float4 *)(region + row * EPI_LD + c4);
-            if (m >= g.M || n >= g.N) continue;
-            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-            if (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
+                *(bf16x8 *)((bf16_t *)g.C + (size_t)m * g.ldc + n) = o;
+            } else if constexpr (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
                 float4 *p = (float4 *)((float *)g.C + (size_t)m * g.ldc + n);
                 const float4 c = *p;
-                *p = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
-            } else if (EPI == SGCLIP_EPI_PATCH_F32) {
+                *p = make_float4(c.x + v[0], c.y + v[1], c.z + v[2], c.w + v[3]);
+            } else if constexpr (EPI == SGCLIP_EPI_PATCH_F32) {
                 const int P = g.aux_rows;
                 const int img = m / P, pp = m - img * P;
                 const size_t orow = (size_t)img * (P + 1) + 1 + pp;
                 const float4 a = *(const float4 *)(g.aux + (size_t)(1 + pp) * g.ldc + n);
-                *(float4 *)((float *)g.C + orow * g.ldc + n) = make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+                *(float4 *)((float *)g.C + orow * g.ldc + n) = make_float4(v[0] + a.x, v[1] + a.y, v[2] + a.z, v[3] + a.w);
             } else {
-                *(float4 *)((float *)g.C + (size_t)m * g.ldc + n) = v;
+                *(float4 *)((float *)g.C + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             }
-        }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -442,14 +437,14 @@ __global__ __launch_bounds__(512, 4) void gemm_ring32_kernel(GemmArgs g) {
     }
     if (g.wide_epilogue) {
         __syncthreads();
-        epilogue_passes<EPI, 4>(g, acc, (float *)(lds + wave * EPI_PASS_BYTES), m0 + wm * 64, n0 + wn * 64, lane);
+        epilogue_passes<EPI, 4, 4>(g, acc, (float *)(lds + wave * epi_pass_bytes(4)), m0 + wm * 64, n0 + wn * 64, lane);
     } else {
         epilogue<EPI>(g, acc, m0 + wm * 64, n0 + wn * 64, frow, fq);
     }
 }
 
 // ---------------------------------------------------------------------------
-// 256 x 256 tile, 8 waves (2 x 4) of 128 x 64, K step 32, 4-slot ring of 32 KiB.
+// 256 x 256 tile, 8 waves (4 x 2) of 64 rows x 128 columns, K step 32, 4-slot ring of 32 KiB.
 // The larger wave tile needs 12 fragment reads per 32 MFMAs (the 64 x 64 tile: 8 per 16) and
 // the larger block tile halves the DMA bytes per MFMA, which takes the LDS off the critical
 // path; used when the grid still fills the chip.
@@ -463,16 +458,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 rows x 128 columns
     const int swz = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = swz / g.tiles_n, tn = swz - tm * g.tiles_n;
     const int m0 = tm * 256, n0 = tn * 256;
 
-    f32x4 acc[8][4];
+    f32x4 acc[4][8];
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // 32 pieces per tile: piece = wave + 8 i; i = 0, 1 -> A, i = 2, 3 -> W
     auto stage = [&](int kt, unsigned char *slot) {
@@ -500,30 +495,30 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
         if (kt + 3 < nk) stage(kt + 3, lds + ((slot + 3) & 3) * BIG_SLOT);
         const unsigned char *la = lds + slot * BIG_SLOT;
         const unsigned char *lb = la + BIG_A;
-        bf16x8 af[8], bfr[4];
+        bf16x8 af[4], bfr[8];
 #pragma unroll
-        for (int j = 0; j < 4; j++) bfr[j] = *(const bf16x8 *)(lb + lds_off32<128>(wn * 64 + j * 16 + frow, fq));
+        for (int i = 0; i < 4; i++) af[i] = *(const bf16x8 *)(la + lds_off32<128>(wm * 64 + i * 16 + frow, fq));
 #pragma unroll
-        for (int i = 0; i < 8; i++) af[i] = *(const bf16x8 *)(la + lds_off32<128>(wm * 128 + i * 16 + frow, fq));
+        for (int j = 0; j < 8; j++) bfr[j] = *(const bf16x8 *)(lb + lds_off32<128>(wn * 128 + j * 16 + frow, fq));
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < 8; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         slot = (slot + 1) & 3;
     }
     if (g.debug_mode == 1) {
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc[i][j]));
+            for (int j = 0; j < 8; j++) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
     if (g.wide_epilogue) {
         __syncthreads();
-        epilogue_passes<EPI, 8>(g, acc, (float *)(lds + wave * EPI_PASS_BYTES), m0 + wm * 128, n0 + wn * 64, lane);
+        epilogue_passes<EPI, 4, 8>(g, acc, (float *)(lds + wave * epi_pass_bytes(8)), m0 + wm * 64, n0 + wn * 128, lane);
     } else {
 #pragma unroll
         for (int half = 0; half < 2; half++) {
@@ -531,8 +526,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) part[i][j] = acc[half * 4 + i][j];
-            epilogue<EPI>(g, part, m0 + wm * 128 + half * 64, n0 + wn * 64, frow, fq);
+                for (int j = 0; j < 4; j++) part[i][j] = acc[i][half * 4 + j];
+            epilogue<EPI>(g, part, m0 + wm * 64, n0 + wn * 128 + half * 64, frow, fq);
         }
     }
 }
