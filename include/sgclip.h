@@ -74,8 +74,9 @@ typedef struct sgclip_crop {
 
 /* luts: host u8[768] = white[256] | keep[256] | tint[256] (level tables of the
  * three blends); norm_lut: host f32[768] = value of level v in channel c at
- * [c*256+v] after rescale+normalize.  frames_dev / masks_dev must be readable
- * up to the next multiple of 4 bytes past frames_bytes / masks_bytes.
+ * [c*256+v] after rescale+normalize.  frames_dev / masks_dev must be 4-byte
+ * aligned and readable for 16 bytes past frames_bytes / masks_bytes (rows are
+ * copied in 16-byte pieces).
  * crops: host table; crops_dev: device buffer of n_crops entries that this
  * call fills (H2D copy on `stream`) unless crops_dev_ready != 0.
  * lut_dev: device scratch of SGCLIP_CROP_LUT_BYTES that this call fills.     */

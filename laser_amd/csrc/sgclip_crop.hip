@@ -1,32 +1,45 @@
 // Mask-guided crop + PIL-compatible bicubic resize + center crop + normalize.
 //
-// One workgroup produces BR output rows of one crop.  It builds the fixed-point
-// resampling coefficients of both axes in LDS (double precision, the exact
-// operation order of Pillow's precompute_coeffs / normalize_coeffs_8bpc), then
-// walks the source rows the band needs in chunks of CH rows:
-//   A  coalesced dword copy of the frame bytes and mask bytes of the chunk into LDS
-//   B  per pixel: mask test + level-table blend -> one packed RGBX dword in LDS
+// One workgroup produces one or more bands of BR output rows of one crop (the
+// host picks bands per workgroup so that the grid still fills the chip).  It
+// builds the fixed-point resampling coefficients of both axes in LDS once
+// (double precision, the exact operation order of Pillow's precompute_coeffs /
+// normalize_coeffs_8bpc), then for every band walks the source rows it needs in
+// chunks of CH rows:
+//   A  asynchronous 16-byte-per-lane copy of the chunk's frame and mask bytes into LDS,
+//      issued one chunk ahead so that it runs underneath C and D
+//   B  per source column, all rows of the chunk: mask test + level-table blend -> packed
+//      RGBX dwords in LDS, a column's CH rows side by side
 //   C  horizontal pass (thread = output column) -> u8 RGBX in LDS
 //   D  vertical pass accumulates into per-thread int32 registers
 // and finally rounds, maps levels through the normalisation table and stores
-// bf16/f32 in CHW or ViT-patch (im2col) layout.  HBM traffic is the crop's own
-// box of frame + mask bytes (re-read only where neighbouring bands overlap by
-// the filter support) plus the output.
+// bf16/f32 in CHW or ViT-patch (im2col) layout (bf16: transposed through LDS and
+// stored 16 bytes per lane).  HBM traffic is the crop's own box of frame + mask
+// bytes (re-read only where neighbouring bands overlap by the filter support)
+// plus the output.
 //
 // Replaces laser/models/model_utils.py:29-56,87-140 and the HF CLIPImageProcessor
 // call at laser/models/llava_clip_model_v3.py:244,443 (PIL Resample.c semantics).
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 namespace sgclip {
 
 constexpr int BR = 16;        // output rows per workgroup
 constexpr int CH = 8;         // source rows per chunk
-constexpr int NT = 256;       // threads per workgroup
+#ifndef CROP_NG
+#define CROP_NG 2
+#endif
+constexpr int NG = CROP_NG;   // thread groups: each takes CH/NG chunk rows in pass C and BR/NG output rows in pass D
+constexpr int COLS = 256;     // output columns per group pass
+constexpr int NT = COLS * NG; // threads per workgroup
+constexpr int CR = CH / NG, DR = BR / NG;
 constexpr int PREC = 22;      // Pillow PRECISION_BITS for 8-bit images
 constexpr int LDS_LIMIT = 160 * 1024;
 
@@ -37,7 +50,8 @@ struct CropLds {
 
 __host__ __device__ inline int al16(int v) { return (v + 15) & ~15; }
 
-__host__ __device__ inline CropLds crop_lds(int S, int ksx, int ksy, int wn) {
+// vrows = output rows one workgroup produces (bands per workgroup * BR)
+__host__ __device__ inline CropLds crop_lds(int S, int ksx, int ksy, int wn, int vrows) {
     CropLds L;
     int o = 0;
     L.lut8 = o; o += 768;
@@ -45,16 +59,21 @@ __host__ __device__ inline CropLds crop_lds(int S, int ksx, int ksy, int wn) {
     L.xmin = o; o += al16(S * 4);
     L.xcnt = o; o += al16(S * 4);
     L.kh = o; o += al16(ksx * S * 4);
-    L.ymin = o; o += al16(BR * 4);
-    L.ycnt = o; o += al16(BR * 4);
-    L.kv = o; o += al16(BR * ksy * 4);
-    L.raw_stride = al16(wn * 3 + 8);
-    L.m_stride = al16(wn + 8);
+    L.ymin = o; o += al16(vrows * 4);
+    L.ycnt = o; o += al16(vrows * 4);
+    L.kv = o; o += al16(vrows * ksy * 4);
+    // a staged row holds the source bytes from the 4-byte boundary below its first
+    // pixel, copied in whole 16-byte pieces
+    L.raw_stride = al16(wn * 3 + 3);
+    L.m_stride = al16(wn + 3);
     L.raw = o; o += CH * L.raw_stride;
     L.ma = o; o += CH * L.m_stride;
     L.mb = o; o += CH * L.m_stride;
-    L.pix = o; o += al16(CH * wn * 4);
+    L.pix = o; o += CH * wn * 4;  // [source column][chunk row]
     L.hbuf = o; o += al16(CH * S * 4);
+    // a band's bf16 output is transposed through pix/hbuf once they are idle
+    const int out_stage = BR * 3 * S * 2;
+    if (o - L.pix < out_stage) o = L.pix + out_stage;
     L.total = o;
     return L;
 }
@@ -144,18 +163,19 @@ struct CropArgs {
     const float *normlut;
     void *out;
     int S, nbands, layout, patch, kpad, out_dtype;
+    int bands_per_wg;      // divides nbands; a workgroup walks this many consecutive bands
     int ksx_cap, ksy_cap, wn_cap;
     int need_lo, need_hi;  // this launch handles the crops whose own LDS need is in (need_lo, need_hi]
 };
 
 // LDS bytes one crop needs when staged with exactly its own tap counts and source span
-__host__ __device__ inline int crop_need(int w, int h, int S) {
+__host__ __device__ inline int crop_need(int w, int h, int S, int vrows) {
     int new_w, new_h, top, left;
     crop_geom(w, h, S, new_w, new_h, top, left);
     int x0, n0, x1, n1;
     axis_bounds(w, new_w, left, x0, n0);
     axis_bounds(w, new_w, left + S - 1, x1, n1);
-    return crop_lds(S, axis_ksize(w, new_w), axis_ksize(h, new_h), x1 + n1 - x0).total;
+    return crop_lds(S, axis_ksize(w, new_w), axis_ksize(h, new_h), x1 + n1 - x0, vrows).total;
 }
 
 __device__ __forceinline__ int clip8(int v) {
@@ -163,24 +183,35 @@ __device__ __forceinline__ int clip8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
+// Hides a thread index from loop-invariant code motion: address arithmetic derived from
+// the result is redone where it is used instead of living in registers across the kernel.
+__device__ __forceinline__ int fresh(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 template <int CPT>
-__global__ __launch_bounds__(NT) void crop_kernel(CropArgs a) {
+__global__ __launch_bounds__(NT, 4) void crop_kernel(CropArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int crop_i = blockIdx.x / a.nbands;
-    const int band = blockIdx.x - crop_i * a.nbands;
+    const int grp = tid / COLS, gcol = tid % COLS;  // grp is wave-uniform
+    const int bpw = a.bands_per_wg;
+    const int wg_per_crop = a.nbands / bpw;
+    const int crop_i = blockIdx.x / wg_per_crop;
+    const int band0 = (blockIdx.x - crop_i * wg_per_crop) * bpw;
+    const int vrows = bpw * BR;
     const sgclip_crop_t c = a.crops[crop_i];
     const int S = a.S;
     const int w = c.x2 - c.x1, h = c.y2 - c.y1;
     {   // crops are binned by LDS need so that small crops run at high occupancy
-        const int need = crop_need(w, h, S);
+        const int need = crop_need(w, h, S, vrows);
         if (need <= a.need_lo || need > a.need_hi) return;
     }
     int new_w, new_h, top, left;
     crop_geom(w, h, S, new_w, new_h, top, left);
 
-    const CropLds L = crop_lds(S, a.ksx_cap, a.ksy_cap, a.wn_cap);
+    const CropLds L = crop_lds(S, a.ksx_cap, a.ksy_cap, a.wn_cap, vrows);
     uint8_t *lut8 = smem + L.lut8;
     float *norm = (float *)(smem + L.norm);
     int *xmin = (int *)(smem + L.xmin);
@@ -195,9 +226,12 @@ __global__ __launch_bounds__(NT) void crop_kernel(CropArgs a) {
     unsigned *pix = (unsigned *)(smem + L.pix);
     unsigned *hbuf = (unsigned *)(smem + L.hbuf);
 
-    for (int i = tid; i < 768; i += NT) {
-        lut8[i] = a.lut8[i];
-        norm[i] = a.normlut[i];
+    // ---- setup: level tables and both axes' coefficients (once per workgroup)
+    if (tid < 192) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a.lut8 + tid * 4), LDS_PTR(lut8 + wave * 256), 4, 0, 0);
+    if (tid < 256) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a.normlut + i * 256 + tid), LDS_PTR(norm + i * 256 + wave * 64), 4, 0, 0);
     }
     for (int col = tid; col < S; col += NT) {
         int xm, n;
@@ -205,168 +239,283 @@ __global__ __launch_bounds__(NT) void crop_kernel(CropArgs a) {
         xmin[col] = xm;
         xcnt[col] = n;
     }
-    if (tid < BR) {
+    // vertical axis from the top thread down: those threads have no column
+    for (int vr = NT - 1 - tid; vr < vrows; vr += NT) {
         int ym, n;
-        axis_coeffs(h, new_h, top + band * BR + tid, ym, n, kv + tid * a.ksy_cap, 1);
-        ymin[tid] = ym;
-        ycnt[tid] = n;
+        axis_coeffs(h, new_h, top + band0 * BR + vr, ym, n, kv + vr, vrows);
+        ymin[vr] = ym;
+        ycnt[vr] = n;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int cx0 = xmin[0];
-    const int wn = xmin[S - 1] + xcnt[S - 1] - cx0;
-    const int ry0 = ymin[0];
-    const int ry1 = ymin[BR - 1] + ycnt[BR - 1];
-    const int wn_cap = a.wn_cap;
-    if (wn > wn_cap) return;  // host sizing guarantees this never triggers
+    const int cx0 = __builtin_amdgcn_readfirstlane(xmin[0]);
+    const int wn = __builtin_amdgcn_readfirstlane(xmin[S - 1] + xcnt[S - 1]) - cx0;
+    if (wn > a.wn_cap) return;  // host sizing guarantees this never triggers
 
-    int vacc[CPT][BR][3];
+    int hx[CPT], hn[CPT];  // this thread's columns: first source pixel (relative) and tap count
 #pragma unroll
-    for (int cc = 0; cc < CPT; cc++)
-#pragma unroll
-        for (int rr = 0; rr < BR; rr++)
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) vacc[cc][rr][ch] = 1 << (PREC - 1);
+    for (int cc = 0; cc < CPT; cc++) {
+        const int col = min(gcol + cc * COLS, S - 1);
+        hx[cc] = xmin[col] - cx0;
+        hn[cc] = xcnt[col];
+    }
 
     const int mode = c.mode;
     const uint8_t *fbase = a.frames + c.frame_off;
     const uint8_t *mabase = a.masks + c.mask_a_off;
     const uint8_t *mbbase = a.masks + c.mask_b_off;
 
-    for (int cy = ry0; cy < ry1; cy += CH) {
-        const int nrows = min(CH, ry1 - cy);
-        // ---- A: frame / mask bytes of the chunk -> LDS (wave per row, dword per lane)
+    // A: wave per source row; the load unit writes LDS itself (no registers), so the
+    // copy is asynchronous until the next s_waitcnt vmcnt(0)
+    auto copy_row = [&](const uint8_t *src, int nbytes, uint8_t *dst) {
+        const int lead = (int)((uintptr_t)src & 3);
+        const uint8_t *s0 = src - lead;
+        const int npiece = (lead + nbytes + 15) >> 4;
+        for (int i = 0; i < npiece; i += 64)
+            if (i + lane < npiece)
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(s0 + (size_t)(i + lane) * 16), LDS_PTR(dst + i * 16), 16, 0, 0);
+    };
+    auto issue_chunk = [&](int cy, int cy_end) {
+        const int nrows = min(CH, cy_end - cy);
         for (int r = wave; r < nrows; r += NT / 64) {
             const size_t pix0 = (size_t)(c.y1 + cy + r) * c.frame_w + (c.x1 + cx0);
-            const uint8_t *src = fbase + pix0 * 3;
-            const int lead = (int)((uintptr_t)src & 3);
-            const unsigned *s4 = (const unsigned *)(src - lead);
-            const int ndw = (lead + wn * 3 + 3) >> 2;
-            unsigned *dst = (unsigned *)(raw + r * L.raw_stride);
-            for (int i = lane; i < ndw; i += 64) dst[i] = s4[i];
+            copy_row(fbase + pix0 * 3, wn * 3, raw + r * L.raw_stride);
             if (mode != SGCLIP_CROP_PLAIN) {
-                const uint8_t *msrc = mabase + pix0;
-                const int ml = (int)((uintptr_t)msrc & 3);
-                const unsigned *m4 = (const unsigned *)(msrc - ml);
-                const int mdw = (ml + wn + 3) >> 2;
-                unsigned *md = (unsigned *)(ma + r * L.m_stride);
-                for (int i = lane; i < mdw; i += 64) md[i] = m4[i];
-                if (mode == SGCLIP_CROP_PAIR) {
-                    const uint8_t *bsrc = mbbase + pix0;
-                    const int bl = (int)((uintptr_t)bsrc & 3);
-                    const unsigned *b4 = (const unsigned *)(bsrc - bl);
-                    const int bdw = (bl + wn + 3) >> 2;
-                    unsigned *bd = (unsigned *)(mb + r * L.m_stride);
-                    for (int i = lane; i < bdw; i += 64) bd[i] = b4[i];
-                }
+                copy_row(mabase + pix0, wn, ma + r * L.m_stride);
+                if (mode == SGCLIP_CROP_PAIR) copy_row(mbbase + pix0, wn, mb + r * L.m_stride);
             }
         }
-        __syncthreads();
-        // ---- B: blend -> packed pixels
-        for (int r = wave; r < nrows; r += NT / 64) {
-            const size_t pix0 = (size_t)(c.y1 + cy + r) * c.frame_w + (c.x1 + cx0);
-            const int lead = (int)((uintptr_t)(fbase + pix0 * 3) & 3);
-            const int ml = (int)((uintptr_t)(mabase + pix0) & 3);
-            const int bl = (int)((uintptr_t)(mbbase + pix0) & 3);
-            const uint8_t *rr = raw + r * L.raw_stride + lead;
-            const uint8_t *mr = ma + r * L.m_stride + ml;
-            const uint8_t *br = mb + r * L.m_stride + bl;
-            unsigned *pr = pix + r * wn_cap;
-            for (int p = lane; p < wn; p += 64) {
-                unsigned b0 = rr[3 * p], b1 = rr[3 * p + 1], b2 = rr[3 * p + 2];
-                if (mode == SGCLIP_CROP_OBJECT) {
-                    const int base = mr[p] ? 256 : 0;
-                    b0 = lut8[base + b0];
-                    b1 = lut8[base + b1];
-                    b2 = lut8[base + b2];
-                } else if (mode == SGCLIP_CROP_PAIR) {
-                    const bool red = mr[p] != 0, blue = br[p] != 0;
-                    if (red | blue) {
-                        if (blue) b0 = lut8[512 + b0];
-                        if (red) b2 = lut8[512 + b2];
-                    } else {
-                        b0 = lut8[b0];
-                        b1 = lut8[b1];
-                        b2 = lut8[b2];
-                    }
-                }
-                pr[p] = b0 | (b1 << 8) | (b2 << 16);
-            }
-        }
-        __syncthreads();
-        // ---- C: horizontal pass, thread = output column
-#pragma unroll
-        for (int cc = 0; cc < CPT; cc++) {
-            const int col = tid + cc * NT;
-            if (col < S) {
-                const int xm = xmin[col] - cx0, n = xcnt[col];
-                int acc[CH][3];
-#pragma unroll
-                for (int r = 0; r < CH; r++) acc[r][0] = acc[r][1] = acc[r][2] = 1 << (PREC - 1);
-                for (int t = 0; t < n; t++) {
-                    const int k = kh[t * S + col];
-#pragma unroll
-                    for (int r = 0; r < CH; r++) {
-                        const unsigned px = pix[r * wn_cap + xm + t];
-                        acc[r][0] += __mul24(k, (int)(px & 255u));
-                        acc[r][1] += __mul24(k, (int)((px >> 8) & 255u));
-                        acc[r][2] += __mul24(k, (int)((px >> 16) & 255u));
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < CH; r++)
-                    hbuf[r * S + col] = (unsigned)clip8(acc[r][0]) | ((unsigned)clip8(acc[r][1]) << 8) |
-                                        ((unsigned)clip8(acc[r][2]) << 16);
-            }
-        }
-        __syncthreads();
-        // ---- D: vertical pass, accumulate this chunk's rows
-#pragma unroll
-        for (int cc = 0; cc < CPT; cc++) {
-            const int col = tid + cc * NT;
-            if (col < S) {
-#pragma unroll
-                for (int rr = 0; rr < BR; rr++) {
-                    const int ym = __builtin_amdgcn_readfirstlane(ymin[rr]);
-                    const int n = __builtin_amdgcn_readfirstlane(ycnt[rr]);
-                    const int t0 = max(0, cy - ym), t1 = min(n, cy + nrows - ym);
-                    for (int t = t0; t < t1; t++) {
-                        const int k = kv[rr * a.ksy_cap + t];
-                        const unsigned px = hbuf[(ym + t - cy) * S + col];
-                        vacc[cc][rr][0] += __mul24(k, (int)(px & 255u));
-                        vacc[cc][rr][1] += __mul24(k, (int)((px >> 8) & 255u));
-                        vacc[cc][rr][2] += __mul24(k, (int)((px >> 16) & 255u));
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
+    };
+    auto band_rows = [&](int bl, int &r0, int &r1) {
+        r0 = __builtin_amdgcn_readfirstlane(ymin[bl * BR]);
+        r1 = __builtin_amdgcn_readfirstlane(ymin[bl * BR + BR - 1] + ycnt[bl * BR + BR - 1]);
+    };
 
-    // ---- output
     const int patch = a.patch;
-    const int G = (a.layout == SGCLIP_LAYOUT_PATCHES) ? S / patch : 1;
+    const bool patches = a.layout == SGCLIP_LAYOUT_PATCHES;
+    const int G = patches ? S / patch : 1;
+    const bool wide = a.out_dtype == SGCLIP_DTYPE_BF16 && ((uintptr_t)a.out & 15) == 0 &&
+                      (!patches || ((patch & 7) == 0 && (a.kpad & 7) == 0));
+
+    int ry0, ry1;
+    band_rows(0, ry0, ry1);
+    issue_chunk(ry0, ry1);
+    for (int bl = 0; bl < bpw; bl++) {
+        const int band = band0 + bl;
+        int ym[DR], yn[DR];  // wave-uniform: first source row and tap count of this group's output rows
 #pragma unroll
-    for (int cc = 0; cc < CPT; cc++) {
-        const int col = tid + cc * NT;
-        if (col < S) {
+        for (int rr = 0; rr < DR; rr++) {
+            ym[rr] = __builtin_amdgcn_readfirstlane(ymin[bl * BR + grp * DR + rr]);
+            yn[rr] = __builtin_amdgcn_readfirstlane(ycnt[bl * BR + grp * DR + rr]);
+        }
+        int vacc[CPT][DR][3];
 #pragma unroll
-            for (int rr = 0; rr < BR; rr++) {
-                const int oy = band * BR + rr;
+        for (int cc = 0; cc < CPT; cc++)
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    const float v = norm[ch * 256 + clip8(vacc[cc][rr][ch])];
-                    size_t o;
-                    if (a.layout == SGCLIP_LAYOUT_PATCHES) {
-                        const size_t prow = (size_t)crop_i * G * G + (size_t)(oy / patch) * G + col / patch;
-                        o = prow * a.kpad + (size_t)ch * patch * patch + (oy % patch) * patch + col % patch;
-                    } else {
-                        o = (((size_t)crop_i * 3 + ch) * S + oy) * S + col;
+            for (int rr = 0; rr < DR; rr++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) vacc[cc][rr][ch] = 1 << (PREC - 1);
+        int nry0 = 0, nry1 = 0;
+        if (bl + 1 < bpw) band_rows(bl + 1, nry0, nry1);
+
+        for (int cy = ry0; cy < ry1; cy += CH) {
+            const int nrows = min(CH, ry1 - cy);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // ---- B: blend -> packed pixels; thread = source column, all rows of the chunk, so
+            // that a column's CH pixels sit side by side for pass C (rows past nrows hold
+            // stale bytes whose results are never used)
+            {
+                // offset of a row's first pixel from the 4-byte boundary its copy started at
+                const size_t pix0 = (size_t)(c.y1 + cy) * c.frame_w + (c.x1 + cx0);
+                const int lead0 = (int)((uintptr_t)(fbase + pix0 * 3) & 3), lead_step = (c.frame_w * 3) & 3;
+                const int ml0 = (int)((uintptr_t)(mabase + pix0) & 3), bo0 = (int)((uintptr_t)(mbbase + pix0) & 3);
+                const int m_step = c.frame_w & 3;
+                // RG rows per thread: narrow crops split the chunk's rows over the threads
+                auto blend = [&](auto rg_c) {
+                    constexpr int RG = decltype(rg_c)::value;  // rows per thread
+                    constexpr int RQ = RG < 4 ? RG : 4;        // rows per store
+                    constexpr int XT = NT / (CH / RG);         // threads along x
+                    const int bt = fresh(tid);
+                    const int rbase = (bt / XT) * RG;
+                    for (int x = bt % XT; x < wn; x += XT) {
+#pragma nounroll
+                        for (int r0 = rbase; r0 < rbase + RG; r0 += RQ) {
+                            unsigned o[RQ];
+#pragma unroll
+                            for (int i = 0; i < RQ; i++) {
+                                const int r = r0 + i;
+                                o[i] = 0;
+                                if (r >= nrows) continue;
+                                const int ml = (ml0 + r * m_step) & 3, bo = (bo0 + r * m_step) & 3;
+                                const uint8_t *rb = raw + r * L.raw_stride + ((lead0 + r * lead_step) & 3) + 3 * x;
+                                unsigned b0 = rb[0], b1 = rb[1], b2 = rb[2];
+                                if (mode == SGCLIP_CROP_OBJECT) {
+                                    const int base = ma[r * L.m_stride + ml + x] ? 256 : 0;
+                                    b0 = lut8[base + b0];
+                                    b1 = lut8[base + b1];
+                                    b2 = lut8[base + b2];
+                                } else if (mode == SGCLIP_CROP_PAIR) {
+                                    const bool red = ma[r * L.m_stride + ml + x] != 0;
+                                    const bool blue = mb[r * L.m_stride + bo + x] != 0;
+                                    if (red | blue) {
+                                        if (blue) b0 = lut8[512 + b0];
+                                        if (red) b2 = lut8[512 + b2];
+                                    } else {
+                                        b0 = lut8[b0];
+                                        b1 = lut8[b1];
+                                        b2 = lut8[b2];
+                                    }
+                                }
+                                o[i] = b0 | (b1 << 8) | (b2 << 16);
+                            }
+                            if constexpr (RQ == 1)
+                                pix[x * CH + r0] = o[0];
+                            else if constexpr (RQ == 2)
+                                *(uint2 *)(pix + x * CH + r0) = make_uint2(o[0], o[1]);
+                            else
+                                *(uint4 *)(pix + x * CH + r0) = make_uint4(o[0], o[1], o[2], o[3]);
+                        }
                     }
-                    if (a.out_dtype == SGCLIP_DTYPE_BF16)
-                        ((bf16_t *)a.out)[o] = (bf16_t)v;
-                    else
-                        ((float *)a.out)[o] = v;
+                };
+                if (wn > NT / 2)
+                    blend(std::integral_constant<int, 8>{});
+                else if (wn > NT / 4)
+                    blend(std::integral_constant<int, 4>{});
+                else if (wn > NT / 8)
+                    blend(std::integral_constant<int, 2>{});
+                else
+                    blend(std::integral_constant<int, 1>{});
+            }
+            __syncthreads();
+            // the raw bytes are consumed: refill them underneath C and D
+            if (cy + CH < ry1)
+                issue_chunk(cy + CH, ry1);
+            else if (bl + 1 < bpw)
+                issue_chunk(nry0, nry1);
+            // ---- C: horizontal pass, thread = output column x CR chunk rows
+            if (grp * CR < nrows) {
+                const int ccol = fresh(gcol);
+#pragma unroll
+                for (int cc = 0; cc < CPT; cc++) {
+                    const int col = ccol + cc * COLS;
+                    if (col < S) {
+                        const int xm = hx[cc], n = hn[cc];
+                        int acc[CR][3];
+#pragma unroll
+                        for (int r = 0; r < CR; r++) acc[r][0] = acc[r][1] = acc[r][2] = 1 << (PREC - 1);
+                        for (int t = 0; t < n; t++) {
+                            const int k = kh[t * S + col];
+                            unsigned pxv[CR];
+                            const unsigned *src = pix + (xm + t) * CH + grp * CR;
+                            if constexpr (CR == 8) {
+                                const uint4 q0 = *(const uint4 *)src, q1 = *(const uint4 *)(src + 4);
+                                pxv[0] = q0.x, pxv[1] = q0.y, pxv[2] = q0.z, pxv[3] = q0.w;
+                                pxv[4] = q1.x, pxv[5] = q1.y, pxv[6] = q1.z, pxv[7] = q1.w;
+                            } else if constexpr (CR == 4) {
+                                const uint4 q = *(const uint4 *)src;
+                                pxv[0] = q.x, pxv[1] = q.y, pxv[2] = q.z, pxv[3] = q.w;
+                            } else {
+                                const uint2 q = *(const uint2 *)src;
+                                pxv[0] = q.x, pxv[1] = q.y;
+                            }
+#pragma unroll
+                            for (int r = 0; r < CR; r++) {
+                                const unsigned px = pxv[r];
+                                acc[r][0] += __mul24(k, (int)(px & 255u));
+                                acc[r][1] += __mul24(k, (int)((px >> 8) & 255u));
+                                acc[r][2] += __mul24(k, (int)((px >> 16) & 255u));
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < CR; r++)
+                            hbuf[(grp * CR + r) * S + col] = (unsigned)clip8(acc[r][0]) | ((unsigned)clip8(acc[r][1]) << 8) |
+                                                             ((unsigned)clip8(acc[r][2]) << 16);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- D: vertical pass, thread = output column x DR output rows; accumulate this chunk's rows
+            const int dcol = fresh(gcol);
+#pragma unroll
+            for (int cc = 0; cc < CPT; cc++) {
+                const int col = dcol + cc * COLS;
+                if (col < S) {
+#pragma unroll
+                    for (int rr = 0; rr < DR; rr++) {
+                        const int t0 = max(0, cy - ym[rr]), t1 = min(yn[rr], cy + nrows - ym[rr]);
+                        for (int t = t0; t < t1; t++) {
+                            const int k = kv[t * vrows + bl * BR + grp * DR + rr];
+                            const unsigned px = hbuf[(ym[rr] + t - cy) * S + col];
+                            vacc[cc][rr][0] += __mul24(k, (int)(px & 255u));
+                            vacc[cc][rr][1] += __mul24(k, (int)((px >> 8) & 255u));
+                            vacc[cc][rr][2] += __mul24(k, (int)((px >> 16) & 255u));
+                        }
+                    }
+                }
+            }
+        }
+        ry0 = nry0;
+        ry1 = nry1;
+
+        // ---- output of this band
+        if (wide) {
+            // transpose through LDS so that every lane stores 8 consecutive columns (16 bytes)
+            bf16_t *stage = (bf16_t *)(smem + L.pix);
+            __syncthreads();
+            const int ocol = fresh(gcol);
+#pragma unroll
+            for (int cc = 0; cc < CPT; cc++) {
+                const int col = ocol + cc * COLS;
+                if (col < S) {
+#pragma unroll
+                    for (int rr = 0; rr < DR; rr++)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                            stage[((grp * DR + rr) * 3 + ch) * S + col] = (bf16_t)norm[ch * 256 + clip8(vacc[cc][rr][ch])];
+                }
+            }
+            __syncthreads();
+            const int per_row = S >> 3;
+            for (int v = fresh(tid); v < BR * 3 * per_row; v += NT) {
+                const int line = v / per_row, col = (v - line * per_row) << 3;
+                const int rr = line / 3, ch = line - rr * 3;
+                const int oy = band * BR + rr;
+                size_t o;
+                if (patches) {
+                    const size_t prow = (size_t)crop_i * G * G + (size_t)(oy / patch) * G + col / patch;
+                    o = prow * a.kpad + (size_t)ch * patch * patch + (oy % patch) * patch + col % patch;
+                } else {
+                    o = (((size_t)crop_i * 3 + ch) * S + oy) * S + col;
+                }
+                *(uint4 *)((bf16_t *)a.out + o) = *(const uint4 *)(stage + line * S + col);
+            }
+            continue;
+        }
+        const int scol = fresh(gcol);
+#pragma unroll
+        for (int cc = 0; cc < CPT; cc++) {
+            const int col = scol + cc * COLS;
+            if (col < S) {
+#pragma unroll
+                for (int rr = 0; rr < DR; rr++) {
+                    const int oy = band * BR + grp * DR + rr;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float v = norm[ch * 256 + clip8(vacc[cc][rr][ch])];
+                        size_t o;
+                        if (patches) {
+                            const size_t prow = (size_t)crop_i * G * G + (size_t)(oy / patch) * G + col / patch;
+                            o = prow * a.kpad + (size_t)ch * patch * patch + (oy % patch) * patch + col % patch;
+                        } else {
+                            o = (((size_t)crop_i * 3 + ch) * S + oy) * S + col;
+                        }
+                        if (a.out_dtype == SGCLIP_DTYPE_BF16)
+                            ((bf16_t *)a.out)[o] = (bf16_t)v;
+                        else
+                            ((float *)a.out)[o] = v;
+                    }
                 }
             }
         }
@@ -376,6 +525,15 @@ __global__ __launch_bounds__(NT) void crop_kernel(CropArgs a) {
 }  // namespace sgclip
 
 using namespace sgclip;
+
+// Bands per workgroup: as many as keep roughly four workgroups per CU slot in flight.
+static int pick_bands_per_wg(int n_crops, int nbands) {
+    const long target = 4L * 768;
+    int best = 1;
+    for (int b = 1; b <= nbands; b++)
+        if (nbands % b == 0 && (long)n_crops * (nbands / b) >= target) best = b;
+    return best;
+}
 
 extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_bytes, const uint8_t *masks_dev,
                                       size_t masks_bytes, const sgclip_crop_t *crops, sgclip_crop_t *crops_dev,
@@ -388,8 +546,8 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
         set_error("sgclip_crop_preprocess: null argument");
         return SGCLIP_EINVAL;
     }
-    if (S <= 0 || S % BR != 0 || S > 2 * NT) {
-        set_error("sgclip_crop_preprocess: S=%d must be a multiple of %d and <= %d", S, BR, 2 * NT);
+    if (S <= 0 || S % BR != 0 || S > 2 * COLS) {
+        set_error("sgclip_crop_preprocess: S=%d must be a multiple of %d and <= %d", S, BR, 2 * COLS);
         return SGCLIP_EINVAL;
     }
     if (layout == SGCLIP_LAYOUT_PATCHES) {
@@ -401,56 +559,82 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
         set_error("sgclip_crop_preprocess: unknown layout %d", layout);
         return SGCLIP_EINVAL;
     }
-    if (((uintptr_t)frames_dev & 3) || ((uintptr_t)masks_dev & 3)) {
-        set_error("sgclip_crop_preprocess: frames_dev / masks_dev must be 4-byte aligned");
+    if (((uintptr_t)frames_dev & 3) || ((uintptr_t)masks_dev & 3) || ((uintptr_t)lut_dev & 3)) {
+        set_error("sgclip_crop_preprocess: frames_dev / masks_dev / lut_dev must be 4-byte aligned");
         return SGCLIP_EINVAL;
+    }
+    const int nbands = S / BR;
+    int bpw = pick_bands_per_wg(n_crops, nbands);
+    if (const char *e = getenv("SGCLIP_CROP_BANDS")) {
+        const int v = atoi(e);
+        if (v > 0 && nbands % v == 0) bpw = v;
     }
     // occupancy classes by LDS need: 4 / 3 / 2 / 1 workgroups per CU
     static const int class_hi[4] = {40 * 1024, 53 * 1024, 80 * 1024, LDS_LIMIT};
-    int ksx[4] = {1, 1, 1, 1}, ksy[4] = {1, 1, 1, 1}, wnc[4] = {1, 1, 1, 1}, members[4] = {0, 0, 0, 0};
+    int ksx[4], ksy[4], wnc[4], members[4];
     double algo_bytes = 0;  // per crop: 3hw frame + m*hw mask + out
-    for (int i = 0; i < n_crops; i++) {
-        const sgclip_crop_t &c = crops[i];
-        const int w = c.x2 - c.x1, h = c.y2 - c.y1;
-        if (w <= 0 || h <= 0) {
-            set_error("image bbox issue: crop %d has an empty box [%d:%d, %d:%d]", i, c.y1, c.y2, c.x1, c.x2);
-            return SGCLIP_EBBOX;
-        }
-        if (c.x1 < 0 || c.y1 < 0 || c.x2 > c.frame_w || c.y2 > c.frame_h || c.frame_off < 0 ||
-            (size_t)c.frame_off + (size_t)c.frame_w * c.frame_h * 3 > frames_bytes) {
-            set_error("sgclip_crop_preprocess: crop %d box or frame outside the frame buffer", i);
-            return SGCLIP_EINVAL;
-        }
-        const size_t mbytes = (size_t)c.frame_w * c.frame_h;
-        if (c.mode == SGCLIP_CROP_OBJECT || c.mode == SGCLIP_CROP_PAIR) {
-            if (!masks_dev || c.mask_a_off < 0 || (size_t)c.mask_a_off + mbytes > masks_bytes ||
-                (c.mode == SGCLIP_CROP_PAIR && (c.mask_b_off < 0 || (size_t)c.mask_b_off + mbytes > masks_bytes))) {
-                set_error("sgclip_crop_preprocess: crop %d mask outside the mask buffer", i);
+    for (;;) {
+        bool too_big = false;
+        for (int k = 0; k < 4; k++) ksx[k] = ksy[k] = wnc[k] = 1, members[k] = 0;
+        algo_bytes = 0;
+        for (int i = 0; i < n_crops; i++) {
+            const sgclip_crop_t &c = crops[i];
+            const int w = c.x2 - c.x1, h = c.y2 - c.y1;
+            if (w <= 0 || h <= 0) {
+                set_error("image bbox issue: crop %d has an empty box [%d:%d, %d:%d]", i, c.y1, c.y2, c.x1, c.x2);
+                return SGCLIP_EBBOX;
+            }
+            if (c.x1 < 0 || c.y1 < 0 || c.x2 > c.frame_w || c.y2 > c.frame_h || c.frame_off < 0 ||
+                (size_t)c.frame_off + (size_t)c.frame_w * c.frame_h * 3 > frames_bytes) {
+                set_error("sgclip_crop_preprocess: crop %d box or frame outside the frame buffer", i);
                 return SGCLIP_EINVAL;
             }
-        } else if (c.mode != SGCLIP_CROP_PLAIN) {
-            set_error("sgclip_crop_preprocess: crop %d has unknown mode %d", i, c.mode);
+            const size_t mbytes = (size_t)c.frame_w * c.frame_h;
+            if (c.mode == SGCLIP_CROP_OBJECT || c.mode == SGCLIP_CROP_PAIR) {
+                if (!masks_dev || c.mask_a_off < 0 || (size_t)c.mask_a_off + mbytes > masks_bytes ||
+                    (c.mode == SGCLIP_CROP_PAIR && (c.mask_b_off < 0 || (size_t)c.mask_b_off + mbytes > masks_bytes))) {
+                    set_error("sgclip_crop_preprocess: crop %d mask outside the mask buffer", i);
+                    return SGCLIP_EINVAL;
+                }
+            } else if (c.mode != SGCLIP_CROP_PLAIN) {
+                set_error("sgclip_crop_preprocess: crop %d has unknown mode %d", i, c.mode);
+                return SGCLIP_EINVAL;
+            }
+            algo_bytes += (3.0 + (c.mode == SGCLIP_CROP_PAIR ? 2 : (c.mode == SGCLIP_CROP_OBJECT ? 1 : 0))) * w * h +
+                          3.0 * S * S * (out_dtype == SGCLIP_DTYPE_BF16 ? 2 : 4);
+            int new_w, new_h, top, left;
+            crop_geom(w, h, S, new_w, new_h, top, left);
+            int x0, n0, x1, n1;
+            axis_bounds(w, new_w, left, x0, n0);
+            axis_bounds(w, new_w, left + S - 1, x1, n1);
+            const int need = crop_need(w, h, S, bpw * BR);
+            if (need > LDS_LIMIT) {
+                if (bpw > 1) {
+                    too_big = true;
+                    break;
+                }
+                set_error("sgclip_crop_preprocess: crop %d needs %d bytes of LDS staging (limit %d): source span %d px", i,
+                          need, LDS_LIMIT, x1 + n1 - x0);
+                return SGCLIP_EINVAL;
+            }
+            int k = 0;
+            while (need > class_hi[k]) k++;
+            ksx[k] = std::max(ksx[k], axis_ksize(w, new_w));
+            ksy[k] = std::max(ksy[k], axis_ksize(h, new_h));
+            wnc[k] = std::max(wnc[k], x1 + n1 - x0);
+            members[k]++;
+        }
+        if (!too_big) {
+            // a class's shared capacities can exceed its bound (taps from one crop, span from another)
+            for (int k = 0; k < 4; k++)
+                if (members[k] && crop_lds(S, ksx[k], ksy[k], wnc[k], bpw * BR).total > LDS_LIMIT) too_big = true;
+        }
+        if (!too_big) break;
+        if (bpw == 1) {
+            set_error("sgclip_crop_preprocess: an LDS class exceeds %d bytes", LDS_LIMIT);
             return SGCLIP_EINVAL;
         }
-        algo_bytes += (3.0 + (c.mode == SGCLIP_CROP_PAIR ? 2 : (c.mode == SGCLIP_CROP_OBJECT ? 1 : 0))) * w * h +
-                      3.0 * S * S * (out_dtype == SGCLIP_DTYPE_BF16 ? 2 : 4);
-        int new_w, new_h, top, left;
-        crop_geom(w, h, S, new_w, new_h, top, left);
-        int x0, n0, x1, n1;
-        axis_bounds(w, new_w, left, x0, n0);
-        axis_bounds(w, new_w, left + S - 1, x1, n1);
-        const int need = crop_need(w, h, S);
-        if (need > LDS_LIMIT) {
-            set_error("sgclip_crop_preprocess: crop %d needs %d bytes of LDS staging (limit %d): source span %d px", i, need,
-                      LDS_LIMIT, x1 + n1 - x0);
-            return SGCLIP_EINVAL;
-        }
-        int k = 0;
-        while (need > class_hi[k]) k++;
-        ksx[k] = std::max(ksx[k], axis_ksize(w, new_w));
-        ksy[k] = std::max(ksy[k], axis_ksize(h, new_h));
-        wnc[k] = std::max(wnc[k], x1 + n1 - x0);
-        members[k]++;
+        bpw = 1;  // per-band coefficient tables are the smallest layout
     }
     uint8_t *lut8_dev = (uint8_t *)lut_dev;
     float *norm_dev = (float *)(lut8_dev + 768);
@@ -470,12 +654,13 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
     a.normlut = norm_dev;
     a.out = out_dev;
     a.S = S;
-    a.nbands = S / BR;
+    a.nbands = nbands;
+    a.bands_per_wg = bpw;
     a.layout = layout;
     a.patch = patch;
     a.kpad = kpad;
     a.out_dtype = out_dtype;
-    const dim3 grid((unsigned)n_crops * a.nbands), block(NT);
+    const dim3 grid((unsigned)n_crops * (nbands / bpw)), block(NT);
     KernelTimer timer(TK_CROP, algo_bytes, stream);
     for (int k = 0; k < 4; k++) {
         if (!members[k]) continue;
@@ -484,13 +669,8 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
         a.wn_cap = wnc[k];
         a.need_lo = k ? class_hi[k - 1] : 0;
         a.need_hi = class_hi[k];
-        // a class's shared capacities can exceed its bound (taps from one crop, span from another)
-        const int lds_bytes = crop_lds(S, ksx[k], ksy[k], wnc[k]).total;
-        if (lds_bytes > LDS_LIMIT) {
-            set_error("sgclip_crop_preprocess: LDS class %d needs %d bytes", k, lds_bytes);
-            return SGCLIP_EINVAL;
-        }
-        if (S <= NT) {
+        const int lds_bytes = crop_lds(S, ksx[k], ksy[k], wnc[k], bpw * BR).total;
+        if (S <= COLS) {
             (void)hipFuncSetAttribute((const void *)crop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
             hipLaunchKernelGGL(crop_kernel<1>, grid, block, lds_bytes, stream, a);
         } else {

@@ -98,7 +98,7 @@ def _host_table_ptr(entries) -> int:
     return C.addressof(entries)
 
 
-PAD = 16  # slack bytes appended to frame / mask buffers (the kernel reads whole dwords)
+PAD = 16  # slack bytes appended to frame / mask buffers (the kernel copies rows in 16-byte pieces)
 
 
 def pad_bytes(flat_u8: np.ndarray) -> np.ndarray:

@@ -223,8 +223,10 @@ def test_crop_matches_golden_and_oracle(dev):
     assert torch.equal(outp.float().cpu(), want)
 
 
-def test_crop_random_boxes_vs_oracle(dev):
-    """Seeded random frames / boxes incl. heavy down-scaling, odd alignments, 1-2 px wide crops; S = 64 and 336."""
+@pytest.mark.parametrize("bands", ["auto", "mid", "all"])
+def test_crop_random_boxes_vs_oracle(dev, bands, monkeypatch):
+    """Seeded random frames / boxes incl. heavy down-scaling, odd alignments, 1-2 px wide crops; S = 64 and 336;
+    one, a few and all bands of a crop per workgroup; f32 stores and the LDS-transposed bf16 stores."""
     from oracle import crop_ref, resample_ref
     rng = np.random.default_rng(5)
     H, W = 333, 517
@@ -244,7 +246,12 @@ def test_crop_random_boxes_vs_oracle(dev):
         rows.append((f * H * W * 3, a * H * W, b * H * W, W, H, x1, y1, x2, y2, mode))
     ent = _entries(rows)
     for S, alpha, wa in ((64, 0.5, 0.8), (336, 0.3, 0.65)):
-        out = ops.crop_preprocess(frames_t, masks_t, ent, S, alpha=alpha, white_alpha=wa).cpu().numpy()
+        if bands != "auto":
+            monkeypatch.setenv("SGCLIP_CROP_BANDS", str(S // 16 if bands == "all" else (2 if S == 64 else 3)))
+        out_t = ops.crop_preprocess(frames_t, masks_t, ent, S, alpha=alpha, white_alpha=wa)
+        out16 = ops.crop_preprocess(frames_t, masks_t, ent, S, alpha=alpha, white_alpha=wa, out_dtype=_lib.DTYPE_BF16)
+        assert torch.equal(out16, out_t.to(torch.bfloat16))
+        out = out_t.cpu().numpy()
         for i, r in enumerate(rows):
             foff, aoff, boff, _, _, x1, y1, x2, y2, mode = r
             fr = frames[foff // (H * W * 3)]
