@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsgclip_hip.so")
+# SGCLIP_LIB names another build of the same library (kernel experiments); the default is the in-tree one
+LIB_PATH = os.environ.get("SGCLIP_LIB") or os.path.join(_HERE, "libsgclip_hip.so")
 
 OK, EINVAL, ENOSPC, ELAUNCH, EBBOX = 0, -1, -2, -3, -4
 

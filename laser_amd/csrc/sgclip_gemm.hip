@@ -308,6 +308,11 @@ __device__ __forceinline__ int lds_off32(int row, int c) {
     return lrow * 128 + ((pos ^ ((lrow >> 1) & 7)) << 4);
 }
 
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // 16-row passes of the coalesced epilogue: LDS bytes per wave for NJ column blocks
 constexpr int epi_pass_bytes(int nj) { return 16 * (nj * 16 + 4) * 4; }
 
@@ -340,10 +345,9 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
         for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int e = 0; e < 4; e++) region[(fq * 4 + e) * LDW + j * 16 + frow] = acc[i][j][e];
-        // the region is private to this wave: order the LDS writes before the reads of other lanes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // the region is private to this wave: its LDS writes only have to precede the reads of its
+        // other lanes (a memory fence here would also wait for the previous pass's global stores)
+        wave_lds_sync();
 #pragma unroll
         for (int rr = 0; rr < 16 / RPI; rr++) {
             const int row = rr * RPI + rl;
@@ -374,9 +378,7 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
                 *(float4 *)((float *)g.C + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_lds_sync();
     }
 }
 
