@@ -177,6 +177,37 @@ int sgclip_segment_mean(const float *probs_dev, const int32_t *seg_ids_dev, int 
                         void *stream);
 
 /* ------------------------------------------------------------------------
+ * (5) Data formats either side of the path.
+ *
+ * sgclip_topk_columns: for every column n of probs[K][N] (row stride ld) the k
+ * best rows, best first, ranked by (value, tie_rank[row]) descending - the order
+ * sorted((p, name), reverse=True) gives in compute_metrics
+ * (scripts/eval_sgclip.py:112-115,132-133,161-164,170-171) when tie_rank is the
+ * rank of the row's name in ascending string order (NULL: lower row first).
+ * out_idx / out_val: [k][N]; rows beyond K hold -1 / 0.  k <= 16.
+ *
+ * sgclip_mask_unpack: bit-packed masks (rows padded to whole bytes, most
+ * significant bit first = numpy.packbits(mask, axis=-1)) -> byte-per-pixel
+ * masks at out_dev + out_off (the layout sgclip_crop_preprocess reads), and per
+ * mask boxes_dev[i] = {x1, y1, x2, y2, count}: the inclusive tight box of
+ * bitmasks2bboxes (laser/loading.py:84-104) and the pixel count of the
+ * minimum-size filter (laser/training/llava_dataset.py:135); an empty mask
+ * gives {INT_MAX, INT_MAX, -1, -1, 0}.  masks: host table; masks_dev: device
+ * buffer of n_masks records that this call fills (H2D copy on `stream`).
+ * ---------------------------------------------------------------------- */
+int sgclip_topk_columns(const float *probs_dev, int64_t ld, int K, int N, const int32_t *tie_rank_dev, int k,
+                        int32_t *out_idx_dev, float *out_val_dev, void *stream);
+
+typedef struct sgclip_mask {
+    int64_t packed_off; /* byte offset of the packed mask inside packed_dev   */
+    int64_t out_off;    /* byte offset of the unpacked u8[H,W] mask inside out_dev */
+    int32_t H, W;
+} sgclip_mask_t; /* 24 bytes */
+int sgclip_mask_unpack(const uint8_t *packed_dev, size_t packed_bytes, const sgclip_mask_t *masks,
+                       sgclip_mask_t *masks_dev, int n_masks, uint8_t *out_dev, size_t out_bytes,
+                       int32_t *boxes_dev, void *stream);
+
+/* ------------------------------------------------------------------------
  * Building blocks, exported for unit tests and profiling.
  * ---------------------------------------------------------------------- */
 #define SGCLIP_EPI_BIAS_BF16 0      /* C_bf16 = A W^T + bias                   */

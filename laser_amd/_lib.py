@@ -33,6 +33,10 @@ class CropEntry(C.Structure):
                 ("mode", C.c_int32), ("reserved", C.c_int32)]
 
 
+class MaskEntry(C.Structure):
+    _fields_ = [("packed_off", C.c_int64), ("out_off", C.c_int64), ("H", C.c_int32), ("W", C.c_int32)]
+
+
 class TowerDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("hidden", C.c_int32), ("ffn", C.c_int32), ("layers", C.c_int32),
                 ("heads", C.c_int32), ("tokens", C.c_int32), ("proj", C.c_int32), ("patch", C.c_int32),
@@ -61,6 +65,10 @@ SIGNATURES = {
     "sgclip_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "sgclip_segment_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "sgclip_topk_columns": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "sgclip_mask_unpack": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_void_p]),
     "sgclip_gemm_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "sgclip_linear_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -233,6 +233,25 @@ def segment_mean(probs: torch.Tensor, seg_ids: torch.Tensor, G: int) -> torch.Te
     return out
 
 
+TOPK_MAX = 16  # largest k of sgclip_topk_columns
+
+
+def topk_columns(probs: torch.Tensor, k: int, tie_rank: Optional[torch.Tensor] = None):
+    """k best rows of every column of probs [K, N], best first: (idx int32 [k, N], val f32 [k, N]).
+    Ties rank by tie_rank[row] descending (None: lower row first)."""
+    lib = _lib.load()
+    if probs.dim() != 2 or probs.dtype != torch.float32 or probs.stride(1) != 1:
+        raise ValueError("topk_columns expects a row-major f32 [K, N] tensor")
+    K, N = probs.shape
+    idx = torch.empty((k, N), dtype=torch.int32, device=probs.device)
+    val = torch.empty((k, N), dtype=torch.float32, device=probs.device)
+    tr = tie_rank.to(probs.device, torch.int32).contiguous() if tie_rank is not None else None
+    _lib.check(lib.sgclip_topk_columns(probs.data_ptr(), probs.stride(0) if K > 1 else max(N, 1), K, N, _ptr(tr), k,
+                                       idx.data_ptr(), val.data_ptr(), _stream()))
+    idx._sgclip_keepalive = (tr, probs)
+    return idx, val
+
+
 # ---------------------------------------------------------------------------
 # building blocks (tests / profiling)
 # ---------------------------------------------------------------------------

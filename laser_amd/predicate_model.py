@@ -21,6 +21,7 @@ from torch import nn
 
 from . import _lib, ops
 from .config import ClipConfig, config_by_name
+from .masks import PackedMasks, unpack_to_device
 from .prob_dict import ProbDict
 from .weights import TOWER_PREFIXES, random_state_dict
 
@@ -79,9 +80,17 @@ class DeviceInputs:
     """Frames and masks of one forward() call resident in HBM."""
 
     def __init__(self, frames: torch.Tensor, frame_off: List[int], frame_hw: List[tuple], masks: Optional[torch.Tensor],
-                 mask_off: List[int], mask_ndim: List[int]):
+                 mask_off: List[int], mask_ndim: List[int], unpacked=None):
         self.frames, self.frame_off, self.frame_hw = frames, frame_off, frame_hw
         self.masks, self.mask_off, self.mask_ndim = masks, mask_off, mask_ndim
+        self.unpacked = unpacked  # laser_amd.masks.UnpackedMasks when the masks arrived bit-packed
+
+    def bbox_dicts(self):
+        """Boxes of bit-packed masks, computed on the GPU, in the reference's dict form
+        (laser/loading.py:84-104); usable as forward()'s batched_bboxes."""
+        if self.unpacked is None:
+            raise ValueError("boxes are only derived for masks staged from PackedMasks")
+        return self.unpacked.bbox_dicts()
 
 
 class PredicateModel(nn.Module):
@@ -142,7 +151,8 @@ class PredicateModel(nn.Module):
     # -- inputs ----------------------------------------------------------------
     def stage_inputs(self, batched_videos, batched_masks) -> DeviceInputs:
         """Upload frames (u8[H,W,3]) and masks (anything `.astype(bool)` accepts, [H,W,1]
-        or [H,W]) into two flat device buffers."""
+        or [H,W]; or a `laser_amd.masks.PackedMasks`, uploaded as bits and expanded on the
+        GPU) into two flat device buffers."""
         frame_off, frame_hw, chunks, off = [], [], [], 0
         for f in batched_videos:
             f = np.ascontiguousarray(f)
@@ -152,6 +162,10 @@ class PredicateModel(nn.Module):
             off += f.size
         chunks.append(np.zeros(ops.PAD, dtype=np.uint8))
         frames = torch.from_numpy(np.concatenate(chunks)).to(self.device, non_blocking=True)
+        if isinstance(batched_masks, PackedMasks):
+            un = unpack_to_device(batched_masks, self.device)
+            return DeviceInputs(frames, frame_off, frame_hw, un.masks if len(batched_masks) else None, un.offsets,
+                                un.ndims, unpacked=un)
         mask_off, mask_ndim, mchunks, off = [], [], [], 0
         for m in batched_masks:
             m = np.asarray(m)
@@ -216,6 +230,8 @@ class PredicateModel(nn.Module):
         if device_inputs is None:
             device_inputs = self.stage_inputs(batched_videos, batched_masks)
         di = device_inputs
+        if batched_bboxes is None:                       # bit-packed masks: boxes come from the unpack kernel
+            batched_bboxes = di.bbox_dicts()
         obj_index = {}                                   # (vid, fid, oid) -> position in batched_object_ids
         ids_lookup: Dict[int, list] = {v: [] for v in range(B)}
         per_vid_rows: Dict[int, list] = {v: [] for v in range(B)}
