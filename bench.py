@@ -142,6 +142,37 @@ def timing_read(kind):
     return ms.value, n.value, work.value
 
 
+def calibrate(device):
+    """What this box sustains on the two roofline axes: a device-to-device stream copy and a large
+    square bf16 GEMM of this library (random operands), next to the vendor peaks used for `frac`."""
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device).random_(0, 255)
+    dst = torch.empty_like(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst.copy_(src)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    M = 8192
+    A = torch.randn(M, M, device=device).to(torch.bfloat16)
+    W = (torch.randn(M, M, device=device) * M ** -0.5).to(torch.bfloat16)
+    bias = torch.zeros(M, device=device)
+    C = torch.empty(M, M, device=device, dtype=torch.bfloat16)
+    ops.gemm_bf16(A, W, C, _lib.EPI_BIAS_BF16, bias=bias)
+    e0.record()
+    for _ in range(5):
+        ops.gemm_bf16(A, W, C, _lib.EPI_BIAS_BF16, bias=bias)
+    e1.record()
+    torch.cuda.synchronize()
+    tf = 5 * 2.0 * M ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return {"stream_copy_GBps": copy_gbs, "hbm_peak_GBps": HBM_PEAK_GBS, "gemm_8192_bf16_TFLOPs": tf,
+            "mfma_peak_TFLOPs": MFMA_PEAK_TFLOPS}
+
+
 def cpu_baseline(args, cfg, sd, tok, batch):
     """The CPU oracle (a port of the reference path) on a bounded sample of the same clip:
     frame 0 with all its objects and the first --cpu-sample-pairs pairs."""
@@ -276,6 +307,8 @@ def main():
         "kernel_ms_per_step": step_ms_timed,
         "whole_step_tflops": encodes_per_step * cfg.vit_flops_per_encode() / (ms_per_step * 1e-3) / 1e12,
     }
+    if rank == 0 and world == 1:
+        result["calibration"] = calibrate(device)
     if args.forward_api and world == 1:
         kw = batch.forward_kwargs()
         model(**kw)
@@ -292,6 +325,19 @@ def main():
             model(**kw, device_inputs=staged)
         torch.cuda.synchronize()
         dt2 = (time.perf_counter() - t0) / 2
+        from laser_amd.masks import pack_masks
+        packed = pack_masks(batch.batched_masks)            # done once, off line (the on-disk format)
+        kwp = dict(kw, batched_masks=packed, batched_bboxes=None)
+        model(**kwp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            model(**kwp)
+        torch.cuda.synchronize()
+        dt3 = (time.perf_counter() - t0) / 2
+        result["forward_api_packed_masks"] = {"host_inputs_ms": dt3 * 1e3, "host_inputs_crops_per_s": crops_per_step / dt3,
+                                              "mask_bytes_uploaded": packed.nbytes,
+                                              "note": "masks arrive bit-packed; unpack + boxes on the GPU"}
         result["forward_api"] = {"host_inputs_ms": dt * 1e3, "host_inputs_crops_per_s": crops_per_step / dt,
                                  "staged_inputs_ms": dt2 * 1e3, "staged_inputs_crops_per_s": crops_per_step / dt2,
                                  "note": "PredicateModel.forward(): host index build + lazy mappings; host_inputs also "
