@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--objects", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=240)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the all-gather even with one rank (rehearsal)")
     ap.add_argument("--forward-api", action="store_true",
                     help="also time PredicateModel.forward() from host numpy inputs (PCIe + host index build included)")
     return ap.parse_args()
@@ -217,7 +219,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
