@@ -231,6 +231,11 @@ int sgclip_layernorm(const float *x_dev, int64_t x_stride, const int32_t *row_id
 /* qkv: bf16 [n_seq*T, 3d]; out: bf16 [n_seq*T, d]; softmax(q k^T / 8 + mask) v per head. */
 int sgclip_attention(const void *qkv_dev, void *out_dev, int n_seq, int T, int heads, int causal,
                      const int32_t *key_mask_dev, void *stream);
+/* The same attention for ONE query per sequence, the row q_rows_dev[s] (global row index into qkv):
+ * out: bf16 [n_seq, d].  Used for the last encoder layer, of which only the pooled token
+ * (class token / end-of-text token) reaches the output (modeling_clip.py:650-651, 574-581). */
+int sgclip_attention_pooled(const void *qkv_dev, const int32_t *q_rows_dev, void *out_dev, int n_seq, int T,
+                            int heads, int causal, const int32_t *key_mask_dev, void *stream);
 
 #ifdef __cplusplus
 }

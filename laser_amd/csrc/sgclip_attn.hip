@@ -23,6 +23,7 @@ struct AttnArgs {
     const bf16_t *qkv;
     bf16_t *out;
     const int32_t *key_mask;  // [n_seq, T] or null
+    const int32_t *q_rows;    // null, or [n_seq]: the one query row (global row index) of every sequence
     int n_seq, T, heads, causal;
     int d;        // heads * 64
     int q_tiles;  // ceil(T / 32)
@@ -33,8 +34,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t vlds[ATT_WAVES][32 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    // blockIdx.x = item_group * q_tiles + qt ; the 4 waves of a block share qt so their
-    // key loops have equal trip counts (the block barrier inside the loop is uniform)
+    // blockIdx.x = item_group * q_tiles + qt
     const int qt = blockIdx.x % a.q_tiles;
     long long item = (long long)(blockIdx.x / a.q_tiles) * ATT_WAVES + wave;
     const bool live = item < a.n_items;
@@ -47,8 +47,10 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_kernel(AttnArgs a) {
     const bf16_t *vbase = qbase + 2 * a.d;
     const int32_t *kmask = a.key_mask ? a.key_mask + (size_t)seq * T : nullptr;
 
-    const int m0 = qt * 32;
-    const int m = m0 + r;
+    // pooled mode: a single query per sequence (every lane row carries it, row 0 is stored)
+    const bool pooled = a.q_rows != nullptr;
+    const int m0 = pooled ? a.q_rows[seq] - seq * T : qt * 32;
+    const int m = pooled ? m0 : m0 + r;
     const int mrow = m < T ? m : T - 1;
     bf16x8 qf[4];
 #pragma unroll
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_kernel(AttnArgs a) {
     float m_run = NEG_BIG, l_run = 0.f;
 
     int n_end = T;
-    if (a.causal) n_end = min(T, m0 + 32);
+    if (a.causal) n_end = min(T, pooled ? m0 + 1 : m0 + 32);
     const int n_blocks = (n_end + 31) / 32;
     bf16_t *vt = vlds[wave];
 
@@ -78,7 +80,16 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_kernel(AttnArgs a) {
             const int vr = min(n0 + 8 * t + (lane >> 3), T - 1);
             vreg[t] = *(const bf16x8 *)(vbase + (size_t)vr * ld + (lane & 7) * 8);
         }
-        __syncthreads();  // every wave has finished reading the previous V tile
+        // The V tile is private to this wave and LDS operations of one wave execute in order, so
+        // wave-level ordering suffices.  The full kernel still uses the block barrier (its four waves
+        // have equal trip counts): keeping them in step measured faster; pooled causal rows differ in
+        // trip count and must not meet at a block barrier.
+        if (pooled) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
 #pragma unroll
         for (int t = 0; t < 4; t++) *(bf16x8 *)(vt + (8 * t + (lane >> 3)) * 64 + (lane & 7) * 8) = vreg[t];
 
@@ -123,7 +134,12 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_kernel(AttnArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; j++) pb[s2][j] = (bf16_t)st[8 * s2 + j];
 
-        __syncthreads();  // V tile written by all lanes of this wave (and block)
+        if (pooled) {  // V tile written by all lanes of this wave
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            __syncthreads();
+        }
         // V^T fragments (A operand): element j of k-step s2 is V[16 s2 + 8 (j>>2) + 4 h + (j&3)][32 dt + r]
         const int i16 = lane & 15, g16 = (lane >> 4) & 1;
         const int tq = i16 >> 2, tp = i16 & 3;
@@ -145,9 +161,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_kernel(AttnArgs a) {
         }
     }
 
-    if (live && m < T) {
+    if (live && (pooled ? r == 0 : m < T)) {
         const float inv = 1.0f / l_run;
-        bf16_t *orow = a.out + ((size_t)seq * T + m) * a.d + head * 64;
+        bf16_t *orow = a.out + (pooled ? (size_t)seq : (size_t)seq * T + m) * a.d + head * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; dt++) {
 #pragma unroll
@@ -165,8 +181,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_kernel(AttnArgs a) {
 
 using namespace sgclip;
 
-extern "C" int sgclip_attention(const void *qkv_dev, void *out_dev, int n_seq, int T, int heads, int causal,
-                                const int32_t *key_mask_dev, void *stream_) {
+static int attention_launch(const void *qkv_dev, const int32_t *q_rows_dev, void *out_dev, int n_seq, int T, int heads,
+                            int causal, const int32_t *key_mask_dev, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_seq == 0) return SGCLIP_OK;
     if (!qkv_dev || !out_dev || n_seq < 0 || T <= 0 || heads <= 0) {
@@ -177,12 +193,13 @@ extern "C" int sgclip_attention(const void *qkv_dev, void *out_dev, int n_seq, i
     a.qkv = (const bf16_t *)qkv_dev;
     a.out = (bf16_t *)out_dev;
     a.key_mask = key_mask_dev;
+    a.q_rows = q_rows_dev;
     a.n_seq = n_seq;
     a.T = T;
     a.heads = heads;
     a.causal = causal;
     a.d = heads * 64;
-    a.q_tiles = ceil_div(T, 32);
+    a.q_tiles = q_rows_dev ? 1 : ceil_div(T, 32);
     a.n_items = (long long)n_seq * heads;
     const long long groups = (a.n_items + ATT_WAVES - 1) / ATT_WAVES;
     const long long blocks = groups * a.q_tiles;
@@ -190,7 +207,21 @@ extern "C" int sgclip_attention(const void *qkv_dev, void *out_dev, int n_seq, i
         set_error("sgclip_attention: grid too large");
         return SGCLIP_EINVAL;
     }
-    KernelTimer timer(TK_ATTN, 4.0 * n_seq * heads * (double)T * T * 64, stream);
+    KernelTimer timer(TK_ATTN, 4.0 * n_seq * heads * (double)(q_rows_dev ? 1 : T) * T * 64, stream);
     hipLaunchKernelGGL(attn_kernel, dim3((unsigned)blocks), dim3(ATT_WAVES * 64), 0, stream, a);
     return launch_check("sgclip_attention");
+}
+
+extern "C" int sgclip_attention(const void *qkv_dev, void *out_dev, int n_seq, int T, int heads, int causal,
+                                const int32_t *key_mask_dev, void *stream) {
+    return attention_launch(qkv_dev, nullptr, out_dev, n_seq, T, heads, causal, key_mask_dev, stream);
+}
+
+extern "C" int sgclip_attention_pooled(const void *qkv_dev, const int32_t *q_rows_dev, void *out_dev, int n_seq, int T,
+                                       int heads, int causal, const int32_t *key_mask_dev, void *stream) {
+    if (!q_rows_dev) {
+        set_error("sgclip_attention_pooled: q_rows_dev is null");
+        return SGCLIP_EINVAL;
+    }
+    return attention_launch(qkv_dev, q_rows_dev, out_dev, n_seq, T, heads, causal, key_mask_dev, stream);
 }

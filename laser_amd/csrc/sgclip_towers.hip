@@ -79,6 +79,20 @@ __global__ void text_embed_kernel(float *x, const float *tok, const float *pos, 
 
 // pooled row per text: first eos position, or argmax of the ids when eos_id == 2
 // (transformers CLIPTextModel.forward, the two pooling branches)
+// rows[k] = k * T: the class token of every image
+__global__ void first_rows_kernel(int K, int T, int32_t *rows) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) rows[k] = k * T;
+}
+
+// dst[s][:] = src[rows[s]][:]
+__global__ void gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ rows, float *__restrict__ dst,
+                                   int d4) {
+    const float4 *s4 = (const float4 *)src + (size_t)rows[blockIdx.x] * d4;
+    float4 *o4 = (float4 *)dst + (size_t)blockIdx.x * d4;
+    for (int i = threadIdx.x; i < d4; i += blockDim.x) o4[i] = s4[i];
+}
+
 __global__ void eos_rows_kernel(const int32_t *ids, int K, int T, int eos_id, int32_t *rows) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
@@ -181,7 +195,9 @@ struct Work {
     bf16_t *h;      // [rows, d] LN output / attention output
     bf16_t *big;    // [rows, max(3d, f)] qkv / mlp hidden
     float *pooled;  // [seqs, d] final LayerNorm output, fp32
-    int32_t *rows;  // [seqs] pooled row index (text)
+    int32_t *rows;  // [seqs] row index of the pooled token (class token / end-of-text token)
+    float *xp;      // [seqs, d] residual stream of the pooled rows through the last layer
+    bf16_t *hp;     // [seqs, d] their attention output / LN output
     size_t total;
 };
 
@@ -196,6 +212,8 @@ static Work carve(const sgclip_tower_desc_t *t, void *base, int64_t seqs, int64_
     w.big = (bf16_t *)(b + take((size_t)rows * wide * 2));
     w.pooled = (float *)(b + take((size_t)seqs * d * 4));
     w.rows = (int32_t *)(b + take((size_t)seqs * 4));
+    w.xp = (float *)(b + take((size_t)seqs * d * 4));
+    w.hp = (bf16_t *)(b + take((size_t)seqs * d * 2));
     w.total = o;
     return w;
 }
@@ -206,10 +224,14 @@ static Work carve(const sgclip_tower_desc_t *t, void *base, int64_t seqs, int64_
         if (_rc != SGCLIP_OK) return _rc; \
     } while (0)
 
+// Only the pooled token of every sequence (w.rows) leaves the tower, so the last layer computes
+// keys and values for all rows but attention output, out-projection and the MLP for those rows
+// alone; the result is the pooled rows' residual stream in w.xp.
 static int run_layers(const sgclip_tower_desc_t *t, const TowerPtrs &P, const Work &w, int seqs, int T, int causal,
                       const int32_t *key_mask, void *stream) {
     const int d = t->hidden, f = t->ffn, M = seqs * T;
-    for (int l = 0; l < t->layers; l++) {
+    const int last = t->layers - 1;
+    for (int l = 0; l < last; l++) {
         CHECK(sgclip_layernorm(w.x, d, nullptr, M, d, P.F(SGCLIP_T_LN1_W, l), P.F(SGCLIP_T_LN1_B, l), t->ln_eps,
                                SGCLIP_DTYPE_BF16, w.h, stream));
         CHECK(sgclip_gemm_bf16(w.h, d, P.B(SGCLIP_T_QKV_W, l), d, w.big, 3 * d, M, 3 * d, d, SGCLIP_EPI_BIAS_BF16,
@@ -222,6 +244,25 @@ static int run_layers(const sgclip_tower_desc_t *t, const TowerPtrs &P, const Wo
         CHECK(sgclip_gemm_bf16(w.h, d, P.B(SGCLIP_T_FC1_W, l), d, w.big, f, M, f, d, SGCLIP_EPI_BIAS_GELU_BF16,
                                P.F(SGCLIP_T_FC1_B, l), nullptr, 0, stream));
         CHECK(sgclip_gemm_bf16(w.big, f, P.B(SGCLIP_T_FC2_W, l), f, w.x, d, M, d, f, SGCLIP_EPI_BIAS_RESID_F32,
+                               P.F(SGCLIP_T_FC2_B, l), nullptr, 0, stream));
+    }
+    {
+        const int l = last;
+        hipStream_t hs = (hipStream_t)stream;
+        CHECK(sgclip_layernorm(w.x, d, nullptr, M, d, P.F(SGCLIP_T_LN1_W, l), P.F(SGCLIP_T_LN1_B, l), t->ln_eps,
+                               SGCLIP_DTYPE_BF16, w.h, stream));
+        CHECK(sgclip_gemm_bf16(w.h, d, P.B(SGCLIP_T_QKV_W, l), d, w.big, 3 * d, M, 3 * d, d, SGCLIP_EPI_BIAS_BF16,
+                               P.F(SGCLIP_T_QKV_B, l), nullptr, 0, stream));
+        CHECK(sgclip_attention_pooled(w.big, w.rows, w.hp, seqs, T, t->heads, causal, key_mask, stream));
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)seqs), dim3(128), 0, hs, w.x, w.rows, w.xp, d / 4);
+        CHECK(launch_check("gather_rows_kernel"));
+        CHECK(sgclip_gemm_bf16(w.hp, d, P.B(SGCLIP_T_O_W, l), d, w.xp, d, seqs, d, d, SGCLIP_EPI_BIAS_RESID_F32,
+                               P.F(SGCLIP_T_O_B, l), nullptr, 0, stream));
+        CHECK(sgclip_layernorm(w.xp, d, nullptr, seqs, d, P.F(SGCLIP_T_LN2_W, l), P.F(SGCLIP_T_LN2_B, l), t->ln_eps,
+                               SGCLIP_DTYPE_BF16, w.hp, stream));
+        CHECK(sgclip_gemm_bf16(w.hp, d, P.B(SGCLIP_T_FC1_W, l), d, w.big, f, seqs, f, d, SGCLIP_EPI_BIAS_GELU_BF16,
+                               P.F(SGCLIP_T_FC1_B, l), nullptr, 0, stream));
+        CHECK(sgclip_gemm_bf16(w.big, f, P.B(SGCLIP_T_FC2_W, l), f, w.xp, d, seqs, d, f, SGCLIP_EPI_BIAS_RESID_F32,
                                P.F(SGCLIP_T_FC2_B, l), nullptr, 0, stream));
     }
     return SGCLIP_OK;
@@ -339,8 +380,10 @@ extern "C" int sgclip_vit_encode(const sgclip_tower_desc_t *desc, const void *w_
         CHECK(launch_check("cls_rows_kernel"));
         CHECK(sgclip_layernorm(w.x, d, nullptr, nc * T, d, Pp.F(SGCLIP_T_PRE_LN_W), Pp.F(SGCLIP_T_PRE_LN_B), desc->ln_eps,
                                SGCLIP_DTYPE_F32, w.x, stream));
+        hipLaunchKernelGGL(first_rows_kernel, dim3(ceil_div(nc, 256)), dim3(256), 0, hs, nc, T, w.rows);
+        CHECK(launch_check("first_rows_kernel"));
         CHECK(run_layers(desc, Pp, w, nc, T, 0, nullptr, stream));
-        CHECK(sgclip_layernorm(w.x, (int64_t)T * d, nullptr, nc, d, Pp.F(SGCLIP_T_POST_LN_W), Pp.F(SGCLIP_T_POST_LN_B),
+        CHECK(sgclip_layernorm(w.xp, d, nullptr, nc, d, Pp.F(SGCLIP_T_POST_LN_W), Pp.F(SGCLIP_T_POST_LN_B),
                                desc->ln_eps, SGCLIP_DTYPE_F32, w.pooled, stream));
         CHECK(sgclip_linear_f32(w.pooled, Pp.F(SGCLIP_T_PROJ_W), nc, E, d, out_dev + (size_t)i0 * E, stream));
     }
@@ -383,7 +426,7 @@ extern "C" int sgclip_text_encode(const sgclip_tower_desc_t *desc, const void *w
                        w.rows);
     CHECK(launch_check("text_embed_kernel"));
     CHECK(run_layers(desc, Pp, w, n_texts, T, 1, attn_mask_dev, stream));
-    CHECK(sgclip_layernorm(w.x, d, w.rows, n_texts, d, Pp.F(SGCLIP_T_POST_LN_W), Pp.F(SGCLIP_T_POST_LN_B), desc->ln_eps,
+    CHECK(sgclip_layernorm(w.xp, d, nullptr, n_texts, d, Pp.F(SGCLIP_T_POST_LN_W), Pp.F(SGCLIP_T_POST_LN_B), desc->ln_eps,
                            SGCLIP_DTYPE_F32, w.pooled, stream));
     CHECK(sgclip_linear_f32(w.pooled, Pp.F(SGCLIP_T_PROJ_W), n_texts, E, d, out_dev, stream));
     return SGCLIP_OK;

@@ -281,3 +281,15 @@ def attention(qkv: torch.Tensor, n_seq: int, T: int, heads: int, causal: bool, k
     _lib.check(lib.sgclip_attention(qkv.data_ptr(), out.data_ptr(), n_seq, T, heads, 1 if causal else 0, _ptr(key_mask),
                                     _stream()))
     return out
+
+
+def attention_pooled(qkv: torch.Tensor, q_rows: torch.Tensor, n_seq: int, T: int, heads: int, causal: bool,
+                     key_mask: Optional[torch.Tensor] = None):
+    """Attention output of one query row per sequence (q_rows: int32 [n_seq], global row indices): bf16 [n_seq, d]."""
+    lib = _lib.load()
+    out = torch.empty((n_seq, heads * 64), dtype=torch.bfloat16, device=qkv.device)
+    qr = q_rows.to(qkv.device, torch.int32).contiguous()
+    _lib.check(lib.sgclip_attention_pooled(qkv.data_ptr(), qr.data_ptr(), out.data_ptr(), n_seq, T, heads,
+                                           1 if causal else 0, _ptr(key_mask), _stream()))
+    out._sgclip_keepalive = (qr,)
+    return out

@@ -126,6 +126,24 @@ def test_attention(dev, n_seq, T, heads, causal):
     assert err < 3e-2, err
 
 
+@pytest.mark.parametrize("n_seq,T,heads,causal", [(5, 50, 12, False), (7, 75, 8, True), (2, 577, 4, False)])
+def test_attention_pooled_equals_the_full_kernel_rows(dev, n_seq, T, heads, causal):
+    d = heads * 64
+    qkv = _rand_bf16((n_seq * T, 3 * d), dev, seed=T)
+    g = torch.Generator().manual_seed(T)
+    pos = torch.randint(0, T, (n_seq,), generator=g)
+    rows = (torch.arange(n_seq) * T + pos).to(torch.int32)
+    key_mask = None
+    if causal:
+        key_mask = torch.ones((n_seq, T), dtype=torch.int32)
+        for s in range(n_seq):
+            key_mask[s, int(pos[s]) + 1:] = 0           # padding after the pooled (end-of-text) token
+        key_mask = key_mask.to(dev)
+    full = ops.attention(qkv, n_seq, T, heads, causal, key_mask)
+    got = ops.attention_pooled(qkv, rows, n_seq, T, heads, causal, key_mask)
+    assert torch.equal(got, full[rows.long().to(dev)])
+
+
 def test_attention_exact_integers(dev):
     """Small-integer q/k/v with one-hot softmax rows: checks the fragment maps exactly."""
     n_seq, T, heads = 2, 50, 2
