@@ -89,9 +89,13 @@ class ClipPlan:
         self.pair_patches = torch.zeros((self.n_pair * P, kpad), dtype=torch.bfloat16, device=device)
         tok = model.clip_tokenizer
         self.tokens = []
-        for kws in (batch.batched_names[0], batch.batched_unary_kws[0], batch.batched_binary_kws[0]):
+        for prefix, kws in (("clip_cate_model", batch.batched_names[0]), ("clip_unary_model", batch.batched_unary_kws[0]),
+                            ("clip_binary_model", batch.batched_binary_kws[0])):
             t = tok(list(kws), return_tensors="pt", max_length=75, truncation=True, padding="max_length")
-            self.tokens.append((t["input_ids"].to(device, torch.int32), t["attention_mask"].to(device, torch.int32)))
+            # positions after the longest keyword's end-of-text token cannot reach any pooled output (causal tower)
+            n_pos = model._packed()[prefix][1].pooled_length(t["input_ids"])
+            self.tokens.append((t["input_ids"][:, :n_pos].to(device, torch.int32).contiguous(),
+                                t["attention_mask"][:, :n_pos].to(device, torch.int32).contiguous(), n_pos))
         self.seg = torch.tensor([oid for (_, _, oid) in batch.batched_object_ids], dtype=torch.int32, device=device)
         self.n_groups = int(self.seg.max()) + 1
         self.algo_crop_bytes = 0.0
@@ -294,7 +298,8 @@ def main():
                                f"ordered pairs/frame at 1280x720, {cfg.image}^2 crops, 35 category + 200 unary + 50 binary "
                                f"keywords, {args.model}, one clip per GPU per step, random-init weights",
                    "crops_per_step_per_gpu": crops_per_step, "image_encodes_per_step_per_gpu": encodes_per_step,
-                   "text_encodes_per_step_per_gpu": 285, "parallelism": f"dp{world} (clips)"},
+                   "text_encodes_per_step_per_gpu": 285,
+                   "text_positions_run": [t[2] for t in plan.tokens], "parallelism": f"dp{world} (clips)"},
         "frames_per_s": world * args.frames * args.steps / elapsed,
         "clip_latency_ms": ms_per_step,
         "roofline": {"kernel": "sgclip::gemm_kernel (bf16 MFMA GEMMs of the three ViT towers + text towers, all epilogues)",

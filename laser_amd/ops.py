@@ -191,8 +191,28 @@ class Tower:
                                          n_images, ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()))
         return out
 
-    def encode_text(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
+    def pooled_length(self, input_ids: torch.Tensor) -> int:
+        """Positions that can influence the pooled (end-of-text) token of any row: the tower is
+        causal, so everything after the pooled position of the longest row is dead computation.
+        Same pooling rule as the reference's text model (modeling_clip.py:561-581)."""
+        ids = input_ids.detach().cpu().numpy()
+        if self.cfg.eos_token_id == 2:
+            pos = ids.argmax(axis=1)
+        else:
+            hit = ids == self.cfg.eos_token_id
+            pos = np.where(hit.any(axis=1), hit.argmax(axis=1), 0)
+        return int(pos.max()) + 1 if len(pos) else 1
+
+    def encode_text(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
+                    seq_len: Optional[int] = None) -> torch.Tensor:
+        """seq_len: leading positions to run (default: `pooled_length` when the ids are on the host,
+        else all of them; callers with device-resident ids pass the value they computed once)."""
         lib = _lib.load()
+        if seq_len is None and input_ids.device.type == "cpu":
+            seq_len = self.pooled_length(input_ids)
+        if seq_len is not None and seq_len < input_ids.shape[1]:
+            input_ids = input_ids[:, :seq_len]
+            attention_mask = None if attention_mask is None else attention_mask[:, :seq_len]
         K, T = input_ids.shape
         ids = input_ids.to(self.device, torch.int32).contiguous()
         am = None if attention_mask is None else attention_mask.to(self.device, torch.int32).contiguous()
