@@ -32,6 +32,18 @@ class PackedMasks:
     def nbytes(self) -> int:
         return int(self.data.nbytes)
 
+    def subset(self, indices: Sequence[int]) -> "PackedMasks":
+        """The masks `indices`, in that order, as a new container."""
+        chunks, offsets, off = [], [], 0
+        for i in indices:
+            H, W = self.shapes[i]
+            n = H * ((W + 7) // 8)
+            chunks.append(self.data[self.offsets[i]: self.offsets[i] + n])
+            offsets.append(off)
+            off += n
+        data = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8)
+        return PackedMasks(data, offsets, [self.shapes[i] for i in indices], [self.ndims[i] for i in indices])
+
     def unpack_host(self, i: int) -> np.ndarray:
         """Mask i as a bool array of its original rank ([H,W], [H,W,1] or [1,H,W])."""
         H, W = self.shapes[i]

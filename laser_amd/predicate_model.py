@@ -206,7 +206,10 @@ class PredicateModel(nn.Module):
                 batched_object_ids, batched_unary_kws, batched_binary_kws, batched_obj_pairs, batched_video_splits,
                 batched_binary_predicates, unary_segment_size=None, binary_segment_size=None, alpha=0.5,
                 white_alpha=0.8, topk_cate=3, dummy_str="$$$", multi_class=False, output_logit=False,
-                output_embeddings=False, device_inputs: Optional[DeviceInputs] = None):
+                output_embeddings=False, device_inputs: Optional[DeviceInputs] = None, allow_dummy_pair: bool = True):
+        """Reference signature (llava_clip_model_v3.py:86-107) plus two optional extras: `device_inputs`
+        (frames / masks already staged in HBM) and `allow_dummy_pair` (False: a call without any pair
+        scores no whole-frame stand-in, for shards of a larger call that does have pairs)."""
         towers = self._packed()
         dev = self.device
         B = len(batched_video_ids)
@@ -342,7 +345,7 @@ class PredicateModel(nn.Module):
             xa, ya, xb, yb = slice_box(x1, y1, x2, y2, W, H, batched_video_ids)
             pair_rows[vid].append((di.frame_off[fidx], di.mask_off[pa], di.mask_off[pb], W, H, xa, ya, xb, yb,
                                    _lib.CROP_PAIR, 0))
-        if len(selected) == 0:                          # default image when no pair exists (:416-420)
+        if len(selected) == 0 and allow_dummy_pair:     # default image when no pair exists (:416-420)
             selected.append((0, -1, (-1, -1)))
             new_select[0] = [(0, -1, (-1, -1))]
             H, W = di.frame_hw[0]

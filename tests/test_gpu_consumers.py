@@ -145,3 +145,56 @@ def test_load_checkpoint_file(tmp_path):
     for v in a[0]:
         assert torch.equal(a[0][v].values_tensor(), b[0][v].values_tensor())
         assert torch.equal(a[1][v].values_tensor(), b[1][v].values_tensor())
+
+
+@pytest.mark.parametrize("name,packed", [("tiny_infer", False), ("tiny_infer", True), ("tiny_no_pairs", False)])
+def test_frame_sharded_forward_equals_the_whole_call(name, packed):
+    """Two ranks' shards scored one after the other on this GPU, merged, against the unsharded call."""
+    from laser_amd.distributed import FrameShardPlan, local_blocks, merge_frame_shards
+    cfg_name, wseed, _, fk = FORWARD_CASES[name]
+    model = _model(cfg_name, wseed)
+    kw = dict(build_case_batch(name).forward_kwargs(), **fk)
+    if packed:
+        kw["batched_masks"] = masks.pack_masks(kw["batched_masks"])
+    want = model(**kw)
+    for world in (2, 3):
+        plan = FrameShardPlan(kw["batched_object_ids"], kw["batched_obj_pairs"], world)
+        assert sum(1 for r in range(world) if plan.obj_pos[r]) >= 2
+        blocks = []
+        for r in range(world):
+            out = model(**plan.local_kwargs(kw, r)) if plan.obj_pos[r] else None
+            blocks.append(local_blocks(out, kw, model.device))
+        got = merge_frame_shards(blocks, plan, kw)
+        torch.cuda.synchronize()
+        for part in (0, 1):
+            for v in want[part]:
+                assert list(want[part][v].keys()) == list(got[part][v].keys())
+                if len(want[part][v]):
+                    assert torch.allclose(want[part][v].values_tensor(), got[part][v].values_tensor(), atol=2e-3)
+        assert len(want[2]) == len(got[2])
+        for x, y in zip(want[2], got[2]):
+            assert list(x.keys()) == list(y.keys())
+            if len(x):
+                assert torch.allclose(x.values_tensor(), y.values_tensor(), atol=2e-3)
+        assert abs(float(want[3]) - float(got[3])) < 2e-3
+
+
+def test_forward_frame_sharded_single_rank_process_group():
+    import torch.distributed as dist
+    from laser_amd.distributed import forward_frame_sharded
+    name = "tiny_infer"
+    cfg_name, wseed, _, fk = FORWARD_CASES[name]
+    model = _model(cfg_name, wseed)
+    kw = dict(build_case_batch(name).forward_kwargs(), **fk)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        want, got = model(**kw), forward_frame_sharded(model, **kw)
+        for v in want[0]:
+            assert torch.allclose(want[0][v].values_tensor(), got[0][v].values_tensor(), atol=1e-5)
+            assert torch.equal(want[1][v].values_tensor(), got[1][v].values_tensor())
+        for x, y in zip(want[2], got[2]):
+            assert list(x.keys()) == list(y.keys()) and torch.equal(x.values_tensor(), y.values_tensor())
+    finally:
+        dist.destroy_process_group()
