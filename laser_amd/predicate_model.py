@@ -238,12 +238,15 @@ class PredicateModel(nn.Module):
         obj_index = {}                                   # (vid, fid, oid) -> position in batched_object_ids
         ids_lookup: Dict[int, list] = {v: [] for v in range(B)}
         per_vid_rows: Dict[int, list] = {v: [] for v in range(B)}
+        n_listed = min(len(batched_object_ids), len(batched_bboxes), len(di.mask_off))
+        obj_box = np.zeros((n_listed, 4), dtype=np.int64)  # every object's own box, corners ordered (:100-108)
         for pos, ((vid, fid, oid), bbox) in enumerate(zip(batched_object_ids, batched_bboxes)):
             if pos >= len(di.mask_off):
                 break                                    # zip() in the reference stops at the shortest list
             fidx = splits[vid] + fid
             H, W = di.frame_hw[fidx]
             x1, y1, x2, y2 = resolve_union_box([bbox], batched_video_ids)
+            obj_box[pos] = (x1, y1, x2, y2)
             xa, ya, xb, yb = slice_box(x1, y1, x2, y2, W, H, batched_video_ids)
             per_vid_rows[vid].append((di.frame_off[fidx], di.mask_off[pos], -1, W, H, xa, ya, xb, yb, _lib.CROP_OBJECT, 0))
             obj_index[(vid, fid, oid)] = pos
@@ -252,6 +255,18 @@ class PredicateModel(nn.Module):
         obj_start = np.cumsum([0] + [len(per_vid_rows[v]) for v in range(B)])
         obj_table = np.array(obj_rows, dtype=CROP_DTYPE)
         n_obj = len(obj_rows)
+
+        # per-object groups of the category mean (:296-311), uploaded before any kernel is queued so
+        # that the transfer never waits for the towers
+        groups: Dict[int, tuple] = {}
+        for vid in range(B):
+            group_of, oids = {}, []
+            for (_, oid) in ids_lookup[vid]:
+                if oid not in group_of:
+                    group_of[oid] = len(oids)
+                    oids.append(oid)
+            seg = torch.tensor([group_of[oid] for (_, oid) in ids_lookup[vid]], dtype=torch.int32).to(dev)
+            groups[vid] = (oids, seg)
 
         # Step 3: object crops through the category and unary towers (:233-339)
         cate_feat = unary_feat = None
@@ -287,12 +302,7 @@ class PredicateModel(nn.Module):
                     if nm == dummy_str:
                         dummy_terms.append(unary_dense[r].sum())
                 # per-object mean over frames (:296-311); groups in order of first appearance
-                group_of, oids = {}, []
-                for (_, oid) in object_ids:
-                    if oid not in group_of:
-                        group_of[oid] = len(oids)
-                        oids.append(oid)
-                seg = torch.tensor([group_of[oid] for (_, oid) in object_ids], dtype=torch.int32)
+                oids, seg = groups[vid]
                 cate_mean = ops.segment_mean(cate_dense, seg, len(oids))
                 # a name listed twice pools both rows' probabilities into one mean in the reference (:296-311)
                 uniq: Dict[str, list] = {}
@@ -333,29 +343,48 @@ class PredicateModel(nn.Module):
                                         sel.add((bp_vid, fid, (a, b)))
             selected = list(sel)
         new_select: Dict[int, list] = {v: [] for v in range(B)}
-        pair_rows: Dict[int, list] = {v: [] for v in range(B)}
-        for (vid, fid, (a, b)) in selected:
-            new_select[vid].append((vid, fid, (a, b)))
-            fidx = splits[vid] + fid
-            H, W = di.frame_hw[fidx]
-            pa, pb = obj_index[(vid, fid, a)], obj_index[(vid, fid, b)]   # KeyError as in the reference (:399-400)
-            if di.mask_ndim[pa] != 3 or di.mask_ndim[pb] != 3:
+        for item in selected:
+            new_select[item[0]].append(item)
+        ordered = [item for v in range(B) for item in new_select[v]]       # crops grouped by video, as the towers see them
+        pair_table = np.zeros(len(ordered), dtype=CROP_DTYPE)
+        if ordered:
+            # the whole table at once: union of the two objects' boxes (:93-115), then the pixels that
+            # img[y1:y2, x1:x2] selects (:117)
+            pa = np.fromiter((obj_index[(vid, fid, pr[0])] for (vid, fid, pr) in ordered), dtype=np.int64, count=len(ordered))
+            pb = np.fromiter((obj_index[(vid, fid, pr[1])] for (vid, fid, pr) in ordered), dtype=np.int64, count=len(ordered))
+            ndim = np.asarray(di.mask_ndim)
+            if (ndim[pa] != 3).any() or (ndim[pb] != 3).any():
                 raise IndexError("too many indices for array: pair masks must be 3-dimensional [H,W,1]")
-            x1, y1, x2, y2 = resolve_union_box([batched_bboxes[pa], batched_bboxes[pb]], batched_video_ids)
-            xa, ya, xb, yb = slice_box(x1, y1, x2, y2, W, H, batched_video_ids)
-            pair_rows[vid].append((di.frame_off[fidx], di.mask_off[pa], di.mask_off[pb], W, H, xa, ya, xb, yb,
-                                   _lib.CROP_PAIR, 0))
-        if len(selected) == 0 and allow_dummy_pair:     # default image when no pair exists (:416-420)
+            fidx = np.fromiter((splits[vid] + fid for (vid, fid, _) in ordered), dtype=np.int64, count=len(ordered))
+            hw = np.asarray(di.frame_hw, dtype=np.int64)
+            Hs, Ws = hw[fidx, 0], hw[fidx, 1]
+            x1 = np.minimum(obj_box[pa, 0], obj_box[pb, 0]); y1 = np.minimum(obj_box[pa, 1], obj_box[pb, 1])
+            x2 = np.maximum(obj_box[pa, 2], obj_box[pb, 2]); y2 = np.maximum(obj_box[pa, 3], obj_box[pb, 3])
+
+            def clamp(v, n):                              # slice.indices() for a positive step
+                return np.where(v < 0, np.maximum(v + n, 0), np.minimum(v, n))
+            xa, xb, ya, yb = clamp(x1, Ws), clamp(x2, Ws), clamp(y1, Hs), clamp(y2, Hs)
+            bad = np.nonzero((xb <= xa) | (yb <= ya))[0]
+            if len(bad):
+                i = int(bad[0])
+                raise ValueError(f"crop box [{y1[i]}:{y2[i]}, {x1[i]}:{x2[i]}] selects no pixel of a {Hs[i]}x{Ws[i]} "
+                                 f"frame: {batched_video_ids}")
+            moff = np.asarray(di.mask_off, dtype=np.int64)
+            pair_table["frame_off"] = np.asarray(di.frame_off, dtype=np.int64)[fidx]
+            pair_table["mask_a_off"], pair_table["mask_b_off"] = moff[pa], moff[pb]
+            pair_table["frame_w"], pair_table["frame_h"] = Ws, Hs
+            pair_table["x1"], pair_table["y1"], pair_table["x2"], pair_table["y2"] = xa, ya, xb, yb
+            pair_table["mode"] = _lib.CROP_PAIR
+        elif allow_dummy_pair:                          # default image when no pair exists (:416-420)
             selected.append((0, -1, (-1, -1)))
             new_select[0] = [(0, -1, (-1, -1))]
             H, W = di.frame_hw[0]
-            pair_rows[0] = [(di.frame_off[0], -1, -1, W, H, 0, 0, W, H, _lib.CROP_PLAIN, 0)]
-        all_pair_rows = [r for v in range(B) for r in pair_rows[v]]
-        pair_start = np.cumsum([0] + [len(pair_rows[v]) for v in range(B)])
-        n_pair = len(all_pair_rows)
+            pair_table = np.array([(di.frame_off[0], -1, -1, W, H, 0, 0, W, H, _lib.CROP_PLAIN, 0)], dtype=CROP_DTYPE)
+        pair_start = np.cumsum([0] + [len(new_select[v]) for v in range(B)])
+        n_pair = len(pair_table)
         pair_feat = None
         if n_pair:
-            ppatches = self._crops(di, np.array(all_pair_rows, dtype=CROP_DTYPE), alpha, white_alpha)
+            ppatches = self._crops(di, pair_table, alpha, white_alpha)
             pair_feat = towers["clip_binary_model"][0].encode_images(ppatches, n_pair)
 
         binary_out: List[object] = []
