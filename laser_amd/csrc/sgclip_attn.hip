@@ -30,7 +30,59 @@ struct AttnArgs {
     long long n_items;  // n_seq * heads
 };
 
-__global__ __launch_bounds__(ATT_WAVES * 64) void attn_kernel(AttnArgs a) {
+// One key block of the online softmax, in the base-2 domain (scores * 0.125 * log2 e).
+// st: S^T accumulators of this lane's query (register g = key n0 + (g&3) + 8*(g>>2) + 4*h); on
+// return pb holds exp2(score - running max) as the bf16 B operand of O^T += V^T * P^T.
+// MASKED = false is the interior-block path: every key valid, no comparisons.
+// The output accumulators are rescaled only when some lane's running maximum moved.
+template <bool MASKED>
+__device__ __forceinline__ void online_softmax_step(f32x16 &st, float &m_run, float &l_run, f32x16 &o0, f32x16 &o1,
+                                                    bf16x8 (&pb)[2], int n0, int m, int h, int T, bool causal,
+                                                    const int32_t *kmask) {
+    constexpr float C = 0.125f * 1.4426950408889634f;
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        float t = st[g] * C;
+        if (MASKED) {
+            const int n = n0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            bool ok = n < T;
+            if (causal) ok = ok && (n <= m);
+            if (kmask) ok = ok && (kmask[min(n, T - 1)] != 0);
+            t = ok ? t : NEG_BIG;
+        }
+        st[g] = t;
+        mx = fmaxf(mx, t);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    float psum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        float p = __builtin_amdgcn_exp2f(st[g] - m_new);
+        if (MASKED) p = st[g] > 0.5f * NEG_BIG ? p : 0.f;   // a row with no valid key yet has m_new == NEG_BIG
+        st[g] = p;
+        psum += p;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    if (__ballot(m_new != m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            o0[g] *= alpha;
+            o1[g] *= alpha;
+        }
+        m_run = m_new;
+    }
+    l_run += psum;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) pb[s2][j] = (bf16_t)st[8 * s2 + j];
+}
+
+__global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t vlds[ATT_WAVES][32 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -99,40 +151,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; s++) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
 
-        // scale + mask; register g holds key n0 + (g&3) + 8*(g>>2) + 4*h for query m
-        float mx = NEG_BIG;
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int n = n0 + (g & 3) + 8 * (g >> 2) + 4 * h;
-            bool ok = n < T;
-            if (a.causal) ok = ok && (n <= m);
-            if (kmask) ok = ok && (kmask[min(n, T - 1)] != 0);
-            st[g] = ok ? st[g] * 0.125f : NEG_BIG;
-            mx = fmaxf(mx, st[g]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const float p = st[g] > 0.5f * NEG_BIG ? __expf(st[g] - m_new) : 0.f;
-            st[g] = p;
-            psum += p;
-        }
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            o0[g] *= alpha;
-            o1[g] *= alpha;
-        }
         bf16x8 pb[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++)
-#pragma unroll
-            for (int j = 0; j < 8; j++) pb[s2][j] = (bf16_t)st[8 * s2 + j];
+        if (n0 + 32 > T || kmask || (a.causal && n0 + 31 > m0))
+            online_softmax_step<true>(st, m_run, l_run, o0, o1, pb, n0, m, h, T, a.causal, kmask);
+        else
+            online_softmax_step<false>(st, m_run, l_run, o0, o1, pb, n0, m, h, T, a.causal, kmask);
 
         if (pooled) {  // V tile written by all lanes of this wave
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -177,6 +200,129 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void attn_kernel(AttnArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Long sequences (T >= 128, ViT-L/14@336: T = 577): the four waves of a block take four
+// consecutive 32-query tiles of ONE (sequence, head) and share every 32-key block of K and V
+// through LDS (double buffered, filled one block ahead through registers), so K and V cross
+// the L2 -> CU path once per 128 queries instead of once per 32.
+// K tile image: [32 keys][128 B], 16-byte chunks XOR-swizzled with (key & 7) so that the
+// ds_read_b128 fragment reads (32 keys x one chunk per half wave) are conflict free.
+// V tile image: plain [32 keys][64], read transposed with ds_read_b64_tr_b16 as above.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_shared_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t kt[2][32 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t vts[2][32 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int q_groups = (a.q_tiles + ATT_WAVES - 1) / ATT_WAVES;
+    const int qg = blockIdx.x % q_groups;
+    const long long item = blockIdx.x / q_groups;
+    const int seq = (int)(item / a.heads), head = (int)(item - (long long)seq * a.heads);
+    const int T = a.T;
+    const size_t ld = (size_t)3 * a.d;
+    const bf16_t *qbase = a.qkv + (size_t)seq * T * ld + head * 64;
+    const bf16_t *kbase = qbase + a.d;
+    const bf16_t *vbase = qbase + 2 * a.d;
+    const int32_t *kmask = a.key_mask ? a.key_mask + (size_t)seq * T : nullptr;
+
+    const int qt = qg * ATT_WAVES + wave;
+    const int m0 = qt * 32;
+    const bool active = m0 < T;          // a wave past the end still helps to load K / V
+    const int m = m0 + r;
+    const int mrow = m < T ? m : T - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) qf[s] = *(const bf16x8 *)(qbase + (size_t)mrow * ld + 16 * s + 8 * h);
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int g = 0; g < 16; g++) o0[g] = o1[g] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    // keys the block needs: all of them, or up to its last query when causal
+    const int blk_end = a.causal ? min(T, (qg * ATT_WAVES + ATT_WAVES) * 32) : T;
+    const int n_blocks = (blk_end + 31) / 32;
+    const int my_end = a.causal ? min(T, m0 + 32) : T;
+    const int my_blocks = active ? (my_end + 31) / 32 : 0;
+
+    // this thread's share of a K / V block: row tid >> 3 (32 rows), 16-byte chunk tid & 7
+    const int lrow = threadIdx.x >> 3, lchunk = threadIdx.x & 7;
+    auto fetch = [&](int kb, bf16x8 &kreg, bf16x8 &vreg) {
+        const int row = min(kb * 32 + lrow, T - 1);
+        kreg = *(const bf16x8 *)(kbase + (size_t)row * ld + lchunk * 8);
+        vreg = *(const bf16x8 *)(vbase + (size_t)row * ld + lchunk * 8);
+    };
+    auto stash = [&](int buf, const bf16x8 &kreg, const bf16x8 &vreg) {
+        *(bf16x8 *)(kt[buf] + lrow * 64 + ((lchunk ^ (lrow & 7)) << 3)) = kreg;
+        *(bf16x8 *)(vts[buf] + lrow * 64 + lchunk * 8) = vreg;
+    };
+    bf16x8 kreg, vreg;
+    fetch(0, kreg, vreg);
+    stash(0, kreg, vreg);
+    if (n_blocks > 1) fetch(1, kreg, vreg);
+    __syncthreads();
+
+    for (int kb = 0; kb < n_blocks; kb++) {
+        const int n0 = kb * 32;
+        const bf16_t *kcur = kt[kb & 1], *vcur = vts[kb & 1];
+        if (kb < my_blocks) {
+            bf16x8 kf[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) kf[s] = *(const bf16x8 *)(kcur + r * 64 + (((2 * s + h) ^ (r & 7)) << 3));
+            f32x16 st;
+#pragma unroll
+            for (int g = 0; g < 16; g++) st[g] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; s++) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
+
+            bf16x8 pb[2];
+            if (n0 + 32 > T || kmask || (a.causal && n0 + 31 > m0))
+                online_softmax_step<true>(st, m_run, l_run, o0, o1, pb, n0, m, h, T, a.causal, kmask);
+            else
+                online_softmax_step<false>(st, m_run, l_run, o0, o1, pb, n0, m, h, T, a.causal, kmask);
+
+            const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+            const int tq = i16 >> 2, tp = i16 & 3;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+#pragma unroll
+                for (int dt = 0; dt < 2; dt++) {
+                    const bf16_t *p0 = vcur + (16 * s2 + 4 * h + tq) * 64 + 32 * dt + 16 * g16 + 4 * tp;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)p0);
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(p0 + 8 * 64));
+                    bf16x8 vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    if (dt == 0)
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s2], o0, 0, 0, 0);
+                    else
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s2], o1, 0, 0, 0);
+                }
+            }
+        }
+        // the other buffer was last read in the previous iteration, which every wave has left
+        if (kb + 1 < n_blocks) stash((kb + 1) & 1, kreg, vreg);
+        if (kb + 2 < n_blocks) fetch(kb + 2, kreg, vreg);
+        __syncthreads();
+    }
+
+    if (active && m < T) {
+        const float inv = 1.0f / l_run;
+        bf16_t *orow = a.out + ((size_t)seq * T + m) * a.d + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++) {
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                bf16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = (bf16_t)((dt == 0 ? o0[4 * gq + e] : o1[4 * gq + e]) * inv);
+                *(bf16x4 *)(orow + 32 * dt + 8 * gq + 4 * h) = v;
+            }
+        }
+    }
+}
+
 }  // namespace sgclip
 
 using namespace sgclip;
@@ -201,6 +347,17 @@ static int attention_launch(const void *qkv_dev, const int32_t *q_rows_dev, void
     a.d = heads * 64;
     a.q_tiles = q_rows_dev ? 1 : ceil_div(T, 32);
     a.n_items = (long long)n_seq * heads;
+    if (!q_rows_dev && T >= 128) {
+        const long long q_groups = (a.q_tiles + ATT_WAVES - 1) / ATT_WAVES;
+        const long long nblk = a.n_items * q_groups;
+        if (nblk > 0x7fffffffLL) {
+            set_error("sgclip_attention: grid too large");
+            return SGCLIP_EINVAL;
+        }
+        KernelTimer timer(TK_ATTN, 4.0 * n_seq * heads * (double)T * T * 64, stream);
+        hipLaunchKernelGGL(attn_shared_kernel, dim3((unsigned)nblk), dim3(ATT_WAVES * 64), 0, stream, a);
+        return launch_check("sgclip_attention");
+    }
     const long long groups = (a.n_items + ATT_WAVES - 1) / ATT_WAVES;
     const long long blocks = groups * a.q_tiles;
     if (blocks > 0x7fffffffLL) {

@@ -59,7 +59,7 @@ def crop_preprocess(frames: torch.Tensor, masks: Optional[torch.Tensor], entries
                     patch: int = 0, out_dtype=_lib.DTYPE_F32, alpha: float = 0.5, white_alpha: float = 0.8,
                     mean=CLIP_MEAN, std=CLIP_STD, out: Optional[torch.Tensor] = None,
                     entries_dev: Optional[torch.Tensor] = None, entries_dev_ready: bool = False) -> torch.Tensor:
-    """frames / masks: flat u8 CUDA buffers (with >= 4 bytes of slack at the end, see
+    """frames / masks: flat u8 CUDA buffers (with PAD = 16 bytes of slack at the end, see
     `pad_bytes`); entries: ctypes array of _lib.CropEntry.  Returns [N,3,S,S] (CHW) or
     [N*P, kpad] (patch layout)."""
     lib = _lib.load()

@@ -112,7 +112,10 @@ def _attn_ref(qkv, n_seq, T, heads, causal, key_mask):
 
 
 @pytest.mark.parametrize("n_seq,T,heads,causal", [(3, 50, 12, False), (2, 75, 8, True), (1, 577, 4, False), (5, 17, 2, False),
-                                                  (2, 32, 2, True), (7, 64, 3, False)])
+                                                  (2, 32, 2, True), (7, 64, 3, False),
+                                                  # T >= 128: the kernel that shares K / V blocks between four query tiles
+                                                  (3, 128, 2, False), (2, 200, 3, True), (1, 130, 1, True), (2, 577, 16, False),
+                                                  (2, 257, 2, True)])
 def test_attention(dev, n_seq, T, heads, causal):
     qkv = _rand_bf16((n_seq * T, 3 * heads * 64), dev, 1.0, 5)
     key_mask = None
