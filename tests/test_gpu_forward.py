@@ -126,3 +126,57 @@ def test_vit_l14_336_towers_match_oracle():
     trel = ((tgot - twant).norm(dim=-1) / twant.norm(dim=-1)).max().item()
     assert trel < 1e-2, trel
     print(f"L/14-336: image feature rel err {rel:.2e}, text feature rel err {trel:.2e}")
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_forward_input_variants_vs_oracle(seed):
+    """Seeded variations of the argument forms the reference accepts (list / tuple / ndarray boxes,
+    corners in either order, float and uint8 masks, objects missing from some frames, a subset of
+    the pairs, a repeated object entry, per-video vocabularies of different length): the HIP path
+    against the CPU oracle on identical inputs; key order exact, probabilities within tolerance."""
+    from oracle.forward_ref import OraclePredicateModel
+    from laser_amd.synthetic import make_clip_batch
+    from laser_amd.weights import split_predicate_state_dict
+    cfg = config_by_name("tiny")
+    sd = predicate_model_state_dict(cfg, seed, float(np.log(100.0)))
+    tok = HashTokenizer(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    model = PredicateModel(None, None, "cuda:0", "tiny", tokenizer=tok).eval()
+    model.load_state_dict(sd)
+    b = make_clip_batch(seed, n_videos=2, frames=3, objects=4, H=96, W=128, k_cate=5, k_unary=6, k_binary=4,
+                        min_box=12, max_box=90)
+    kw = b.forward_kwargs()
+    rng = np.random.default_rng(seed)
+    keep = [i for i in range(len(kw["batched_object_ids"])) if rng.random() < 0.8 or i < 2]
+    present = {kw["batched_object_ids"][i] for i in keep}
+    boxes, masks_in = [], []
+    for n, i in enumerate(keep):
+        bb = kw["batched_bboxes"][i]
+        x1, y1, x2, y2 = bb["x1"], bb["y1"], bb["x2"], bb["y2"]
+        form = n % 4
+        boxes.append(bb if form == 0 else [x2, y2, x1, y1] if form == 1 else (x1, y2, x2, y1) if form == 2
+                     else np.array([x1, y1, x2, y2, 0.9]))
+        m = np.asarray(kw["batched_masks"][i])
+        masks_in.append(m.astype(np.float32) if n % 3 == 0 else m.astype(np.uint8) if n % 3 == 1 else m)
+    kw["batched_object_ids"] = [kw["batched_object_ids"][i] for i in keep]
+    kw["batched_bboxes"], kw["batched_masks"] = boxes, masks_in
+    kw["batched_obj_pairs"] = [p for p in kw["batched_obj_pairs"]
+                               if (p[0], p[1], p[2][0]) in present and (p[0], p[1], p[2][1]) in present and rng.random() < 0.7]
+    # the same object listed twice (later entry wins in the dictionaries)
+    kw["batched_object_ids"].append(kw["batched_object_ids"][0])
+    kw["batched_bboxes"].append(kw["batched_bboxes"][0])
+    kw["batched_masks"].append(kw["batched_masks"][0])
+    kw["batched_names"] = [kw["batched_names"][0][:3], kw["batched_names"][1]]
+    fk = dict(multi_class=bool(seed % 2), alpha=0.4, white_alpha=0.7)
+    got = model(**kw, **fk)
+    want = OraclePredicateModel(cfg, split_predicate_state_dict(sd), tok)(**kw, **fk)
+    worst = 0.0
+    for part in (0, 1):
+        for v in want[part]:
+            assert list(got[part][v].keys()) == list(want[part][v].keys())
+            worst = max(worst, compare_prob_dicts(got[part][v], {k: float(x) for k, x in want[part][v].items()}, PROB_TOL))
+    assert len(got[2]) == len(want[2])
+    for g, w in zip(got[2], want[2]):
+        assert list(g.keys()) == list(w.keys())
+        worst = max(worst, compare_prob_dicts(g, {k: float(x) for k, x in w.items()}, PROB_TOL))
+    assert abs(float(got[3]) - float(want[3])) <= PROB_TOL
+    print(f"variants seed {seed}: max |p - oracle| = {worst:.3e}")
