@@ -237,6 +237,59 @@ int sgclip_attention(const void *qkv_dev, void *out_dev, int n_seq, int T, int h
 int sgclip_attention_pooled(const void *qkv_dev, const int32_t *q_rows_dev, void *out_dev, int n_seq, int T,
                             int heads, int causal, const int32_t *key_mask_dev, void *stream);
 
+/* ------------------------------------------------------------------------
+ * (6) Adjoints of the kernels above, for the train step
+ * (scripts/train_sgclip.py:682-694 runs forward() under autograd and :877-890
+ * back-propagates the loss into the CLIP weights).  The matrix products of the
+ * backward pass (data gradient dY W, weight gradient dY^T X) run on
+ * sgclip_gemm_bf16 with transposed operands; these entry points supply the
+ * transposes, reductions and the non-GEMM adjoints.
+ * ---------------------------------------------------------------------- */
+/* out[c][r] = in[r][c], bf16; in [rows, cols] (ld_in), out [cols, ld_out], ld_out >= rows,
+ * columns rows..ld_out-1 zero-filled (pads the reduction dimension of a weight gradient). */
+int sgclip_transpose_bf16(const void *in_dev, int64_t ld_in, int rows, int cols, void *out_dev, int64_t ld_out,
+                          void *stream);
+/* out[n] += sum_m in[m][n] (bias gradients); in bf16 or f32 [M, N] (ld); out f32, caller zeroes it. */
+int sgclip_colsum(const void *in_dev, int in_dtype, int64_t ld, int M, int N, float *out_dev, void *stream);
+/* g = u sigmoid(1.702 u) (modeling_clip.py quick_gelu activation) and du = dg g'(u); bf16, n elements. */
+int sgclip_quick_gelu(const void *u_dev, void *g_dev, int64_t n, void *stream);
+int sgclip_quick_gelu_bwd(const void *u_dev, const void *dg_dev, void *du_dev, int64_t n, void *stream);
+int sgclip_cast_f32_bf16(const float *in_dev, void *out_dev, int64_t n, void *stream);
+/* LayerNorm adjoint.  x f32 [rows, d] (row stride x_stride), dy bf16 or f32 [rows, d];
+ * dx f32 [rows, d] (accumulate_dx: added to what dx holds); dw, db f32 [d], accumulated (caller zeroes). */
+int sgclip_layernorm_bwd(const float *x_dev, int64_t x_stride, int rows, int d, const float *w_dev, float eps,
+                         const void *dy_dev, int dy_dtype, float *dx_dev, int accumulate_dx, float *dw_dev,
+                         float *db_dev, void *stream);
+/* Adjoint of sgclip_attention for T <= 128: qkv bf16 [n_seq*T, 3d], dout bf16 [n_seq*T, d]
+ * -> dqkv bf16 [n_seq*T, 3d]; the probabilities are recomputed, nothing is saved by the forward. */
+int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, void *dqkv_dev, int n_seq, int T, int heads,
+                         int causal, const int32_t *key_mask_dev, void *stream);
+/* C[M][N] (+)= alpha op(A) op(B), fp32; op(A) = A [M,K] or, transA, A^T with A [K,M]; likewise B.
+ * For the small fp32 tail (projection, similarity) where bf16 would cost accuracy. */
+int sgclip_matmul_f32(const float *A_dev, int64_t lda, int transA, const float *B_dev, int64_t ldb, int transB,
+                      float *C_dev, int64_t ldc, int M, int N, int K, float alpha, int accumulate, void *stream);
+/* dlogits [K][N] from dprobs: softmax over k per column n, sigmoid, or copy (mode = SGCLIP_SIM_*). */
+int sgclip_prob_bwd(const float *probs_dev, const float *dprobs_dev, int K, int N, int mode, float *dlogits_dev,
+                    void *stream);
+/* xh = x / |x| per row: dx = (dxh - xh <xh, dxh>) / |x|; [rows, E] f32. */
+int sgclip_normalize_bwd(const float *x_dev, const float *dxhat_dev, int rows, int E, float *dx_dev, void *stream);
+/* xhat = x / |x| per row, [rows, E] f32 (the normalisation inside clip_sim, llava_clip_model_v3.py:43-44). */
+int sgclip_normalize_rows(const float *x_dev, int rows, int E, float *xhat_dev, void *stream);
+/* Adjoint of sgclip_segment_mean: dprobs[k][n] = dmean[k][seg[n]] * inv_count[seg[n]]. */
+int sgclip_segment_mean_bwd(const float *dmean_dev, const int32_t *seg_ids_dev, const float *inv_count_dev, int K, int N,
+                            int G, float *dprobs_dev, void *stream);
+/* Embeddings of the training forward from fp32 tables: x[s*T+t] = table[ids[s*T+t]] + pos[t] (text,
+ * modeling_clip.py:190-207); x[s*T] = cls + pos[0] (class-token row of every image, :160-171). */
+int sgclip_embed_text(const float *table_dev, const float *pos_dev, const int32_t *ids_dev, int n_texts, int T, int d,
+                      float *x_dev, void *stream);
+int sgclip_embed_cls(const float *cls_dev, const float *pos_dev, int n_images, int T, int d, float *x_dev, void *stream);
+/* dst[idx[r]][:] += src[r][:]; f32 rows of d elements (embedding-table gradients). */
+int sgclip_rows_scatter_add(const float *src_dev, const int32_t *idx_dev, int rows, int d, float *dst_dev,
+                            void *stream);
+/* One AdamW step on fp32 parameters (decoupled weight decay; step counts from 1). */
+int sgclip_adamw(float *param_dev, const float *grad_dev, float *m_dev, float *v_dev, int64_t n, float lr,
+                 float beta1, float beta2, float eps, float weight_decay, int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,528 @@
+// Backward building blocks of the train step (scripts/train_sgclip.py:682-694, 877-890 run the
+// same forward() under autograd; the ops below are the adjoints of the kernels of this library).
+// They are correctness-first: plain HBM-bound / VALU kernels around the bf16 MFMA GEMM, which
+// does the heavy data- and weight-gradient products (sgclip_gemm_bf16 on transposed operands).
+#include "common.h"
+
+#include <algorithm>
+
+namespace sgclip {
+
+// ---------------------------------------------------------------------------
+// out[c][r] = in[r][c], bf16, 64 x 64 tiles through LDS; columns rows..ld_out-1 of out are zeroed
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t *__restrict__ in, long long ld_in, int rows,
+                                                             int cols, bf16_t *__restrict__ out, long long ld_out) {
+    __shared__ bf16_t tile[64][66];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : (bf16_t)0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < ld_out) out[(size_t)c * ld_out + r] = tile[tx][i];
+    }
+}
+
+// out[n] += sum over a slice of rows of in[m][n]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ in, long long ld, int M, int N,
+                                                     float *__restrict__ out, int rows_per_block) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float s = 0.f;
+    if (n < N)
+        for (int m = m0 + part; m < m1; m += 4) s += (float)in[(size_t)m * ld + n];
+    __shared__ float red[4][64];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__device__ __forceinline__ float sigmoid1702(float x) { return 1.0f / (1.0f + __expf(-1.702f * x)); }
+
+__global__ void quick_gelu_kernel(const bf16_t *__restrict__ u, bf16_t *__restrict__ g, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float x = (float)u[i];
+        g[i] = (bf16_t)(x * sigmoid1702(x));
+    }
+}
+
+__global__ void quick_gelu_bwd_kernel(const bf16_t *__restrict__ u, const bf16_t *__restrict__ dg, bf16_t *__restrict__ du,
+                                      long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float x = (float)u[i], s = sigmoid1702(x);
+        du[i] = (bf16_t)((float)dg[i] * (s + 1.702f * x * s * (1.0f - s)));
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float *__restrict__ in, bf16_t *__restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (bf16_t)in[i];
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm backward: one wave per row (statistics recomputed from x), dx per row,
+// dw / db reduced over the block's four rows in LDS, then one atomic per column and block.
+//   xh = (x - mean) rstd;  g = dy w;  dx = rstd (g - mean(g) - xh mean(g xh))
+// ---------------------------------------------------------------------------
+template <bool DY_BF16>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ x, long long x_stride, int rows, int d,
+                                                            const float *__restrict__ w, float eps, const void *dy_,
+                                                            float *dx, int accumulate, float *__restrict__ dw,
+                                                            float *__restrict__ db) {
+    extern __shared__ float lds_acc[];  // [2][d]: dw, db partial sums of this block
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 2 * d; i += 256) lds_acc[i] = 0.f;
+    __syncthreads();
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row < rows) {
+        const float *xr = x + (size_t)row * x_stride;
+        float s = 0.f;
+        for (int i = lane; i < d; i += 64) s += xr[i];
+        const float mean = wave_sum(s) / d;
+        float q = 0.f;
+        for (int i = lane; i < d; i += 64) {
+            const float a = xr[i] - mean;
+            q += a * a;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / d + eps);
+        float sg = 0.f, sgx = 0.f;
+        for (int i = lane; i < d; i += 64) {
+            const float dyv = DY_BF16 ? (float)((const bf16_t *)dy_)[(size_t)row * d + i] : ((const float *)dy_)[(size_t)row * d + i];
+            const float xh = (xr[i] - mean) * rstd, g = dyv * w[i];
+            sg += g;
+            sgx += g * xh;
+            atomicAdd(&lds_acc[i], dyv * xh);
+            atomicAdd(&lds_acc[d + i], dyv);
+        }
+        const float mg = wave_sum(sg) / d, mgx = wave_sum(sgx) / d;
+        float *dxr = dx + (size_t)row * d;
+        for (int i = lane; i < d; i += 64) {
+            const float dyv = DY_BF16 ? (float)((const bf16_t *)dy_)[(size_t)row * d + i] : ((const float *)dy_)[(size_t)row * d + i];
+            const float xh = (xr[i] - mean) * rstd;
+            const float v = rstd * (dyv * w[i] - mg - xh * mgx);
+            dxr[i] = accumulate ? dxr[i] + v : v;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += 256) {
+        atomicAdd(dw + i, lds_acc[i]);
+        atomicAdd(db + i, lds_acc[d + i]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Attention backward for short sequences (T <= 128, head_dim 64): one workgroup per
+// (sequence, head); Q, K, V, dO as bf16 and the T x T probabilities as f32 in LDS.
+//   P = softmax(Q K^T / 8 + mask);  dV = P^T dO;  dP = dO V^T;  D_i = sum_k P_ik dP_ik
+//   dS = P (dP - D);  dQ = dS K / 8;  dK = dS^T Q / 8
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+                                                            bf16_t *__restrict__ dqkv, int T, int heads, int causal,
+                                                            const int32_t *__restrict__ key_mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int d = heads * 64;
+    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
+    const size_t ld = (size_t)3 * d;
+    bf16_t *Q = (bf16_t *)smem, *K = Q + T * 64, *V = K + T * 64, *dO = V + T * 64;
+    float *P = (float *)(dO + T * 64);  // [T][T], later dS in place
+    const bf16_t *base = qkv + (size_t)seq * T * ld + head * 64;
+    const int32_t *km = key_mask ? key_mask + (size_t)seq * T : nullptr;
+    for (int i = threadIdx.x; i < T * 64; i += 256) {
+        const int t = i >> 6, c = i & 63;
+        Q[i] = base[(size_t)t * ld + c];
+        K[i] = base[(size_t)t * ld + d + c];
+        V[i] = base[(size_t)t * ld + 2 * d + c];
+        dO[i] = dout[((size_t)seq * T + t) * d + head * 64 + c];
+    }
+    __syncthreads();
+    // scores
+    for (int e = threadIdx.x; e < T * T; e += 256) {
+        const int i = e / T, k = e - i * T;
+        bool ok = true;
+        if (causal) ok = k <= i;
+        if (km) ok = ok && km[k] != 0;
+        float s = 0.f;
+        if (ok) {
+            for (int c = 0; c < 64; c++) s += (float)Q[i * 64 + c] * (float)K[k * 64 + c];
+            s *= 0.125f;
+        }
+        P[e] = ok ? s : -1.0e30f;
+    }
+    __syncthreads();
+    // row softmax: wave per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < T; i += 4) {
+        float mx = -1.0e30f;
+        for (int k = lane; k < T; k += 64) mx = fmaxf(mx, P[i * T + k]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int k = lane; k < T; k += 64) {
+            const float p = P[i * T + k] > -0.5e30f ? __expf(P[i * T + k] - mx) : 0.f;
+            P[i * T + k] = p;
+            sum += p;
+        }
+        sum = wave_sum(sum);
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        for (int k = lane; k < T; k += 64) P[i * T + k] *= inv;
+    }
+    __syncthreads();
+    bf16_t *obase = dqkv + (size_t)seq * T * ld + head * 64;
+    // dV[k][c] = sum_i P[i][k] dO[i][c]
+    for (int e = threadIdx.x; e < T * 64; e += 256) {
+        const int k = e >> 6, c = e & 63;
+        float s = 0.f;
+        for (int i = 0; i < T; i++) s += P[i * T + k] * (float)dO[i * 64 + c];
+        obase[(size_t)k * ld + 2 * d + c] = (bf16_t)s;
+    }
+    __syncthreads();
+    // dS in place: wave per row (needs the whole row of P and dP)
+    for (int i = wave; i < T; i += 4) {
+        float dpv[2];  // T <= 128: at most two keys per lane
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int k = lane + 64 * j;
+            dpv[j] = 0.f;
+            if (k < T) {
+                float s = 0.f;
+                for (int c = 0; c < 64; c++) s += (float)dO[i * 64 + c] * (float)V[k * 64 + c];
+                dpv[j] = s;
+                dsum += P[i * T + k] * s;
+            }
+        }
+        dsum = wave_sum(dsum);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int k = lane + 64 * j;
+            if (k < T) P[i * T + k] = P[i * T + k] * (dpv[j] - dsum) * 0.125f;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * 64; e += 256) {
+        const int t = e >> 6, c = e & 63;
+        float sq = 0.f, sk = 0.f;
+        for (int j = 0; j < T; j++) {
+            sq += P[t * T + j] * (float)K[j * 64 + c];   // dQ[t] = sum_k dS[t][k] K[k]
+            sk += P[j * T + t] * (float)Q[j * 64 + c];   // dK[t] = sum_i dS[i][t] Q[i]
+        }
+        obase[(size_t)t * ld + c] = (bf16_t)sq;
+        obase[(size_t)t * ld + d + c] = (bf16_t)sk;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// C[M][N] (+)= alpha * op(A) op(B), fp32, 64 x 64 tiles (the small products of the fp32 tail:
+// projection, similarity).  op(A) is [M][K]: A[m][k] or, transposed, A[k][m]; likewise op(B) [K][N].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void matmul_f32_kernel(const float *__restrict__ A, long long lda, int transA,
+                                                         const float *__restrict__ B, long long ldb, int transB,
+                                                         float *__restrict__ C, long long ldc, int M, int N, int K,
+                                                         float alpha, int accumulate) {
+    __shared__ float As[16][65], Bs[16][65];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 x 4 outputs each
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+            const int kk = i >> 6, mm = i & 63;
+            const int k = k0 + kk;
+            float a = 0.f, b = 0.f;
+            if (k < K && m0 + mm < M) a = transA ? A[(size_t)k * lda + m0 + mm] : A[(size_t)(m0 + mm) * lda + k];
+            if (k < K && n0 + mm < N) b = transB ? B[(size_t)(n0 + mm) * ldb + k] : B[(size_t)k * ldb + n0 + mm];
+            As[kk][mm] = a;
+            Bs[kk][mm] = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = As[kk][ty * 4 + i], b[i] = Bs[kk][tx * 4 + i];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            if (m < M && n < N) {
+                float *c = C + (size_t)m * ldc + n;
+                *c = accumulate ? *c + alpha * acc[i][j] : alpha * acc[i][j];
+            }
+        }
+}
+
+// dlogits from dprobs: softmax over the rows of every column, sigmoid, or pass-through
+__global__ void prob_bwd_kernel(const float *__restrict__ p, const float *__restrict__ dp, int K, int N, int mode,
+                                float *__restrict__ dl) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    if (mode == SGCLIP_SIM_SOFTMAX) {
+        float dot = 0.f;
+        for (int k = 0; k < K; k++) dot += p[(size_t)k * N + n] * dp[(size_t)k * N + n];
+        for (int k = 0; k < K; k++) dl[(size_t)k * N + n] = p[(size_t)k * N + n] * (dp[(size_t)k * N + n] - dot);
+    } else if (mode == SGCLIP_SIM_SIGMOID) {
+        for (int k = 0; k < K; k++) {
+            const float v = p[(size_t)k * N + n];
+            dl[(size_t)k * N + n] = v * (1.0f - v) * dp[(size_t)k * N + n];
+        }
+    } else {
+        for (int k = 0; k < K; k++) dl[(size_t)k * N + n] = dp[(size_t)k * N + n];
+    }
+}
+
+// xh = x / |x| (rows):  dx = (dxh - xh <xh, dxh>) / |x|;  wave per row
+__global__ __launch_bounds__(256) void normalize_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dxh,
+                                                            int rows, int E, float *__restrict__ dx) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * E, *gr = dxh + (size_t)row * E;
+    float nn = 0.f, dot = 0.f;
+    for (int i = lane; i < E; i += 64) {
+        nn += xr[i] * xr[i];
+        dot += xr[i] * gr[i];
+    }
+    nn = wave_sum(nn);
+    dot = wave_sum(dot);
+    const float inv = rsqrtf(nn);
+    for (int i = lane; i < E; i += 64) dx[(size_t)row * E + i] = (gr[i] - xr[i] * dot / nn) * inv;
+}
+
+// xh = x / |x| per row; wave per row
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const float *__restrict__ x, int rows, int E, float *__restrict__ xh) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * E;
+    float nn = 0.f;
+    for (int i = lane; i < E; i += 64) nn += xr[i] * xr[i];
+    const float inv = 1.0f / sqrtf(wave_sum(nn));
+    for (int i = lane; i < E; i += 64) xh[(size_t)row * E + i] = xr[i] * inv;
+}
+
+// adjoint of the per-group column mean: dprobs[k][n] = dmean[k][seg[n]] * inv_count[seg[n]]
+__global__ void segment_mean_bwd_kernel(const float *__restrict__ dmean, const int32_t *__restrict__ seg,
+                                        const float *__restrict__ inv_count, int K, int N, int G, float *__restrict__ dprobs) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int g = seg[n];
+    const float w = inv_count[g];
+    for (int k = 0; k < K; k++) dprobs[(size_t)k * N + n] = dmean[(size_t)k * G + g] * w;
+}
+
+// x[s*T + t][:] = table[ids[s*T + t]][:] + pos[t][:]   (text embeddings, modeling_clip.py:190-207)
+__global__ void embed_text_kernel(const float *__restrict__ table, const float *__restrict__ pos, const int32_t *__restrict__ ids,
+                                  int T, int d, float *__restrict__ x) {
+    const int row = blockIdx.x, t = row % T;
+    const float *src = table + (size_t)ids[row] * d, *p = pos + (size_t)t * d;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) x[(size_t)row * d + i] = src[i] + p[i];
+}
+
+// x[s*T][:] = cls[:] + pos[0][:]   (class token row of every image, modeling_clip.py:160-171)
+__global__ void embed_cls_kernel(const float *__restrict__ cls, const float *__restrict__ pos, int T, int d, float *__restrict__ x) {
+    for (int i = threadIdx.x; i < d; i += blockDim.x) x[(size_t)blockIdx.x * T * d + i] = cls[i] + pos[i];
+}
+
+// dst[idx[r]][:] += src[r][:]
+__global__ void rows_scatter_add_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx, int d,
+                                        float *__restrict__ dst) {
+    const float *s = src + (size_t)blockIdx.x * d;
+    float *o = dst + (size_t)idx[blockIdx.x] * d;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) atomicAdd(o + i, s[i]);
+}
+
+// AdamW on fp32 master weights (decoupled weight decay)
+__global__ void adamw_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                             long long n, float lr, float b1, float b2, float eps, float wd, float c1, float c2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi, vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] * (1.0f - lr * wd) - lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+}
+
+}  // namespace sgclip
+
+using namespace sgclip;
+
+#define BWD_ARGS_OK(cond, name)                         \
+    if (!(cond)) {                                      \
+        set_error(name ": bad arguments");              \
+        return SGCLIP_EINVAL;                           \
+    }
+
+extern "C" int sgclip_transpose_bf16(const void *in_dev, int64_t ld_in, int rows, int cols, void *out_dev, int64_t ld_out,
+                                     void *stream) {
+    if (rows == 0 || cols == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(in_dev && out_dev && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= rows, "sgclip_transpose_bf16");
+    const dim3 grid(ceil_div((int)ld_out, 64), ceil_div(cols, 64));
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)in_dev,
+                       (long long)ld_in, rows, cols, (bf16_t *)out_dev, (long long)ld_out);
+    return launch_check("sgclip_transpose_bf16");
+}
+
+extern "C" int sgclip_colsum(const void *in_dev, int in_dtype, int64_t ld, int M, int N, float *out_dev, void *stream) {
+    if (M == 0 || N == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(in_dev && out_dev && M > 0 && N > 0 && ld >= N, "sgclip_colsum");
+    const int rpb = std::max(64, ceil_div(M, 512));
+    const dim3 grid(ceil_div(N, 64), ceil_div(M, rpb));
+    if (in_dtype == SGCLIP_DTYPE_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)in_dev,
+                           (long long)ld, M, N, out_dev, rpb);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)in_dev,
+                           (long long)ld, M, N, out_dev, rpb);
+    return launch_check("sgclip_colsum");
+}
+
+extern "C" int sgclip_quick_gelu(const void *u_dev, void *g_dev, int64_t n, void *stream) {
+    if (n == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(u_dev && g_dev && n > 0, "sgclip_quick_gelu");
+    hipLaunchKernelGGL(quick_gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t *)u_dev, (bf16_t *)g_dev, (long long)n);
+    return launch_check("sgclip_quick_gelu");
+}
+
+extern "C" int sgclip_quick_gelu_bwd(const void *u_dev, const void *dg_dev, void *du_dev, int64_t n, void *stream) {
+    if (n == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(u_dev && dg_dev && du_dev && n > 0, "sgclip_quick_gelu_bwd");
+    hipLaunchKernelGGL(quick_gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t *)u_dev, (const bf16_t *)dg_dev, (bf16_t *)du_dev, (long long)n);
+    return launch_check("sgclip_quick_gelu_bwd");
+}
+
+extern "C" int sgclip_cast_f32_bf16(const float *in_dev, void *out_dev, int64_t n, void *stream) {
+    if (n == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(in_dev && out_dev && n > 0, "sgclip_cast_f32_bf16");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in_dev,
+                       (bf16_t *)out_dev, (long long)n);
+    return launch_check("sgclip_cast_f32_bf16");
+}
+
+extern "C" int sgclip_layernorm_bwd(const float *x_dev, int64_t x_stride, int rows, int d, const float *w_dev, float eps,
+                                    const void *dy_dev, int dy_dtype, float *dx_dev, int accumulate_dx, float *dw_dev,
+                                    float *db_dev, void *stream) {
+    if (rows == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(x_dev && w_dev && dy_dev && dx_dev && dw_dev && db_dev && rows > 0 && d > 0 && x_stride >= d,
+                "sgclip_layernorm_bwd");
+    const dim3 grid(ceil_div(rows, 4));
+    const size_t lds = (size_t)2 * d * sizeof(float);
+    if (dy_dtype == SGCLIP_DTYPE_BF16)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, x_dev, (long long)x_stride,
+                           rows, d, w_dev, eps, dy_dev, dx_dev, accumulate_dx, dw_dev, db_dev);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, x_dev, (long long)x_stride,
+                           rows, d, w_dev, eps, dy_dev, dx_dev, accumulate_dx, dw_dev, db_dev);
+    return launch_check("sgclip_layernorm_bwd");
+}
+
+extern "C" int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, void *dqkv_dev, int n_seq, int T, int heads,
+                                    int causal, const int32_t *key_mask_dev, void *stream) {
+    if (n_seq == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(qkv_dev && dout_dev && dqkv_dev && n_seq > 0 && T > 0 && heads > 0, "sgclip_attention_bwd");
+    if (T > 128) {
+        set_error("sgclip_attention_bwd: T=%d > 128 is not supported by the short-sequence backward kernel", T);
+        return SGCLIP_EINVAL;
+    }
+    const size_t lds = (size_t)4 * T * 64 * sizeof(bf16_t) + (size_t)T * T * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3((unsigned)(n_seq * heads)), dim3(256), lds, (hipStream_t)stream,
+                       (const bf16_t *)qkv_dev, (const bf16_t *)dout_dev, (bf16_t *)dqkv_dev, T, heads, causal, key_mask_dev);
+    return launch_check("sgclip_attention_bwd");
+}
+
+extern "C" int sgclip_matmul_f32(const float *A_dev, int64_t lda, int transA, const float *B_dev, int64_t ldb, int transB,
+                                 float *C_dev, int64_t ldc, int M, int N, int K, float alpha, int accumulate, void *stream) {
+    if (M == 0 || N == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(A_dev && B_dev && C_dev && M > 0 && N > 0 && K >= 0 && ldc >= N, "sgclip_matmul_f32");
+    hipLaunchKernelGGL(matmul_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, (hipStream_t)stream, A_dev,
+                       (long long)lda, transA, B_dev, (long long)ldb, transB, C_dev, (long long)ldc, M, N, K, alpha, accumulate);
+    return launch_check("sgclip_matmul_f32");
+}
+
+extern "C" int sgclip_prob_bwd(const float *probs_dev, const float *dprobs_dev, int K, int N, int mode, float *dlogits_dev,
+                               void *stream) {
+    if (K == 0 || N == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(probs_dev && dprobs_dev && dlogits_dev && K > 0 && N > 0, "sgclip_prob_bwd");
+    hipLaunchKernelGGL(prob_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, probs_dev, dprobs_dev, K, N,
+                       mode, dlogits_dev);
+    return launch_check("sgclip_prob_bwd");
+}
+
+extern "C" int sgclip_normalize_bwd(const float *x_dev, const float *dxhat_dev, int rows, int E, float *dx_dev, void *stream) {
+    if (rows == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(x_dev && dxhat_dev && dx_dev && rows > 0 && E > 0, "sgclip_normalize_bwd");
+    hipLaunchKernelGGL(normalize_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x_dev, dxhat_dev, rows,
+                       E, dx_dev);
+    return launch_check("sgclip_normalize_bwd");
+}
+
+extern "C" int sgclip_normalize_rows(const float *x_dev, int rows, int E, float *xhat_dev, void *stream) {
+    if (rows == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(x_dev && xhat_dev && rows > 0 && E > 0, "sgclip_normalize_rows");
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, x_dev, rows, E, xhat_dev);
+    return launch_check("sgclip_normalize_rows");
+}
+
+extern "C" int sgclip_segment_mean_bwd(const float *dmean_dev, const int32_t *seg_ids_dev, const float *inv_count_dev, int K,
+                                       int N, int G, float *dprobs_dev, void *stream) {
+    if (K == 0 || N == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(dmean_dev && seg_ids_dev && inv_count_dev && dprobs_dev && K > 0 && N > 0 && G > 0, "sgclip_segment_mean_bwd");
+    hipLaunchKernelGGL(segment_mean_bwd_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, dmean_dev, seg_ids_dev,
+                       inv_count_dev, K, N, G, dprobs_dev);
+    return launch_check("sgclip_segment_mean_bwd");
+}
+
+extern "C" int sgclip_embed_text(const float *table_dev, const float *pos_dev, const int32_t *ids_dev, int n_texts, int T, int d,
+                                 float *x_dev, void *stream) {
+    if (n_texts == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(table_dev && pos_dev && ids_dev && x_dev && n_texts > 0 && T > 0 && d > 0, "sgclip_embed_text");
+    hipLaunchKernelGGL(embed_text_kernel, dim3((unsigned)(n_texts * T)), dim3(128), 0, (hipStream_t)stream, table_dev, pos_dev,
+                       ids_dev, T, d, x_dev);
+    return launch_check("sgclip_embed_text");
+}
+
+extern "C" int sgclip_embed_cls(const float *cls_dev, const float *pos_dev, int n_images, int T, int d, float *x_dev,
+                                void *stream) {
+    if (n_images == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(cls_dev && pos_dev && x_dev && n_images > 0 && T > 0 && d > 0, "sgclip_embed_cls");
+    hipLaunchKernelGGL(embed_cls_kernel, dim3((unsigned)n_images), dim3(128), 0, (hipStream_t)stream, cls_dev, pos_dev, T, d, x_dev);
+    return launch_check("sgclip_embed_cls");
+}
+
+extern "C" int sgclip_rows_scatter_add(const float *src_dev, const int32_t *idx_dev, int rows, int d, float *dst_dev,
+                                       void *stream) {
+    if (rows == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(src_dev && idx_dev && dst_dev && rows > 0 && d > 0, "sgclip_rows_scatter_add");
+    hipLaunchKernelGGL(rows_scatter_add_kernel, dim3((unsigned)rows), dim3(128), 0, (hipStream_t)stream, src_dev, idx_dev, d,
+                       dst_dev);
+    return launch_check("sgclip_rows_scatter_add");
+}
+
+extern "C" int sgclip_adamw(float *param_dev, const float *grad_dev, float *m_dev, float *v_dev, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int step, void *stream) {
+    if (n == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(param_dev && grad_dev && m_dev && v_dev && n > 0 && step >= 1, "sgclip_adamw");
+    const float c1 = 1.0f - powf(beta1, (float)step), c2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param_dev, grad_dev,
+                       m_dev, v_dev, (long long)n, lr, beta1, beta2, eps, weight_decay, c1, c2);
+    return launch_check("sgclip_adamw");
+}

@@ -1,0 +1,191 @@
+"""Torch-facing wrappers of the backward building blocks of libsgclip_hip.so.
+
+Torch supplies device memory, the stream and views; every arithmetic step of the
+train step's backward pass is one of the calls below (or `ops.gemm_bf16`).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .ops import _ptr, _stream, gemm_bf16
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == BF16:
+        return _lib.DTYPE_BF16
+    if t.dtype == F32:
+        return _lib.DTYPE_F32
+    raise TypeError(f"expected bf16 or f32, got {t.dtype}")
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+def transpose_bf16(x: torch.Tensor, ld_out: Optional[int] = None) -> torch.Tensor:
+    """bf16 [R, C] -> [C, ld_out] with out[c, r] = x[r, c]; columns R..ld_out-1 are zero."""
+    assert x.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1
+    R, Cc = x.shape
+    ld_out = ld_out or R
+    out = torch.empty((Cc, ld_out), dtype=BF16, device=x.device)
+    _lib.check(_lib.load().sgclip_transpose_bf16(x.data_ptr(), x.stride(0), R, Cc, out.data_ptr(), ld_out, _stream()))
+    return out
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f32 [N] (+)= column sums of x [M, N] (bf16 or f32)."""
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, N = x.shape
+    if out is None:
+        out = torch.zeros(N, dtype=F32, device=x.device)
+    _lib.check(_lib.load().sgclip_colsum(x.data_ptr(), _dtype_code(x), x.stride(0), M, N, out.data_ptr(), _stream()))
+    return out
+
+
+def quick_gelu(u: torch.Tensor) -> torch.Tensor:
+    assert u.dtype == BF16 and u.is_contiguous()
+    g = torch.empty_like(u)
+    _lib.check(_lib.load().sgclip_quick_gelu(u.data_ptr(), g.data_ptr(), u.numel(), _stream()))
+    return g
+
+
+def quick_gelu_bwd(u: torch.Tensor, dg: torch.Tensor) -> torch.Tensor:
+    assert u.dtype == BF16 and dg.dtype == BF16 and u.is_contiguous() and dg.is_contiguous() and u.shape == dg.shape
+    du = torch.empty_like(u)
+    _lib.check(_lib.load().sgclip_quick_gelu_bwd(u.data_ptr(), dg.data_ptr(), du.data_ptr(), u.numel(), _stream()))
+    return du
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    assert x.dtype == F32 and x.is_contiguous()
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _lib.check(_lib.load().sgclip_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()))
+    return y
+
+
+def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor, dw: torch.Tensor, db: torch.Tensor,
+                  dx: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """dx (f32 [rows, d]; added to `dx` when accumulate) and dw / db (+=) of y = LayerNorm(x) w + b."""
+    assert x.dtype == F32 and x.dim() == 2 and x.stride(1) == 1 and dy.is_contiguous() and dy.shape == x.shape
+    rows, d = x.shape
+    if dx is None:
+        assert not accumulate
+        dx = torch.empty((rows, d), dtype=F32, device=x.device)
+    assert dx.dtype == F32 and dx.is_contiguous() and dx.shape == x.shape
+    _lib.check(_lib.load().sgclip_layernorm_bwd(x.data_ptr(), x.stride(0), rows, d, w.data_ptr(), eps, dy.data_ptr(),
+                                                _dtype_code(dy), dx.data_ptr(), 1 if accumulate else 0, dw.data_ptr(),
+                                                db.data_ptr(), _stream()))
+    return dx
+
+
+def attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, n_seq: int, T: int, heads: int, causal: bool,
+                  key_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert qkv.dtype == BF16 and dout.dtype == BF16 and qkv.is_contiguous() and dout.is_contiguous()
+    assert qkv.shape == (n_seq * T, 3 * heads * 64) and dout.shape == (n_seq * T, heads * 64)
+    dqkv = torch.empty_like(qkv)
+    _lib.check(_lib.load().sgclip_attention_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), n_seq, T, heads,
+                                                1 if causal else 0, _ptr(key_mask), _stream()))
+    return dqkv
+
+
+def matmul_f32(A: torch.Tensor, B: torch.Tensor, transA: bool = False, transB: bool = False, alpha: float = 1.0,
+               out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """alpha op(A) op(B) in fp32; A, B row-major 2-D."""
+    assert A.dtype == F32 and B.dtype == F32 and A.stride(1) == 1 and B.stride(1) == 1
+    M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+    Kb, N = (B.shape[1], B.shape[0]) if transB else B.shape
+    assert K == Kb, (A.shape, B.shape, transA, transB)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, N), dtype=F32, device=A.device)
+    _lib.check(_lib.load().sgclip_matmul_f32(A.data_ptr(), A.stride(0), 1 if transA else 0, B.data_ptr(), B.stride(0),
+                                             1 if transB else 0, out.data_ptr(), out.stride(0), M, N, K, float(alpha),
+                                             1 if accumulate else 0, _stream()))
+    return out
+
+
+def prob_bwd(probs: torch.Tensor, dprobs: torch.Tensor, mode: int) -> torch.Tensor:
+    assert probs.dtype == F32 and probs.is_contiguous() and dprobs.is_contiguous() and probs.shape == dprobs.shape
+    K, N = probs.shape
+    dl = torch.empty_like(probs)
+    _lib.check(_lib.load().sgclip_prob_bwd(probs.data_ptr(), dprobs.data_ptr(), K, N, mode, dl.data_ptr(), _stream()))
+    return dl
+
+
+def normalize_rows(x: torch.Tensor) -> torch.Tensor:
+    assert x.dtype == F32 and x.is_contiguous() and x.dim() == 2
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().sgclip_normalize_rows(x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), _stream()))
+    return y
+
+
+def normalize_bwd(x: torch.Tensor, dxhat: torch.Tensor) -> torch.Tensor:
+    assert x.dtype == F32 and x.is_contiguous() and dxhat.is_contiguous() and x.shape == dxhat.shape
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().sgclip_normalize_bwd(x.data_ptr(), dxhat.data_ptr(), x.shape[0], x.shape[1], dx.data_ptr(),
+                                                _stream()))
+    return dx
+
+
+def segment_mean_bwd(dmean: torch.Tensor, seg: torch.Tensor, inv_count: torch.Tensor, N: int) -> torch.Tensor:
+    assert dmean.dtype == F32 and dmean.is_contiguous() and seg.dtype == torch.int32 and inv_count.dtype == F32
+    K, G = dmean.shape
+    out = torch.empty((K, N), dtype=F32, device=dmean.device)
+    _lib.check(_lib.load().sgclip_segment_mean_bwd(dmean.data_ptr(), seg.data_ptr(), inv_count.data_ptr(), K, N, G,
+                                                   out.data_ptr(), _stream()))
+    return out
+
+
+def embed_text(table: torch.Tensor, pos: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """f32 [K*T, d] = table[ids] + pos[:T]; ids int32 [K, T] on the device."""
+    assert table.dtype == F32 and pos.dtype == F32 and ids.dtype == torch.int32 and ids.is_contiguous()
+    K, T = ids.shape
+    d = table.shape[1]
+    x = torch.empty((K * T, d), dtype=F32, device=table.device)
+    _lib.check(_lib.load().sgclip_embed_text(table.data_ptr(), pos.data_ptr(), ids.data_ptr(), K, T, d, x.data_ptr(), _stream()))
+    return x
+
+
+def embed_cls(cls: torch.Tensor, pos: torch.Tensor, x: torch.Tensor, n_images: int, T: int):
+    """Writes cls + pos[0] into row 0 of every image of x (f32 [n_images*T, d])."""
+    d = x.shape[1]
+    _lib.check(_lib.load().sgclip_embed_cls(cls.data_ptr(), pos.data_ptr(), n_images, T, d, x.data_ptr(), _stream()))
+
+
+def rows_scatter_add(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor):
+    """dst[idx[r]] += src[r] (f32 rows)."""
+    assert src.dtype == F32 and dst.dtype == F32 and src.is_contiguous() and dst.is_contiguous()
+    assert idx.dtype == torch.int32 and idx.numel() == src.shape[0] and src.shape[1] == dst.shape[1]
+    _lib.check(_lib.load().sgclip_rows_scatter_add(src.data_ptr(), idx.data_ptr(), src.shape[0], src.shape[1], dst.data_ptr(),
+                                                   _stream()))
+
+
+def adamw(param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,
+          beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0):
+    for t in (param, grad, m, v):
+        assert t.dtype == F32 and t.is_contiguous() and t.numel() == param.numel()
+    _lib.check(_lib.load().sgclip_adamw(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), param.numel(), lr,
+                                        beta1, beta2, eps, weight_decay, step, _stream()))
+
+
+# -- linear layers on the MFMA GEMM ---------------------------------------------------------
+def linear_dgrad(dy: torch.Tensor, w_t: torch.Tensor, zero_bias: torch.Tensor) -> torch.Tensor:
+    """dx bf16 [M, in] = dy [M, out] W, with w_t = W^T stored [in, out] (bf16)."""
+    M = dy.shape[0]
+    dx = torch.empty((M, w_t.shape[0]), dtype=BF16, device=dy.device)
+    return gemm_bf16(dy, w_t, dx, _lib.EPI_BIAS_BF16, bias=zero_bias)
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW f32 [out, in] = dy^T x for dy bf16 [M, out], x bf16 [M, in]; M is zero-padded to a multiple of 64."""
+    M = dy.shape[0]
+    Mp = pad64(M)
+    dyt = transpose_bf16(dy, Mp)
+    xt = transpose_bf16(x, Mp)
+    dw = torch.empty((dy.shape[1], x.shape[1]), dtype=F32, device=dy.device)
+    return gemm_bf16(dyt, xt, dw, _lib.EPI_F32)
