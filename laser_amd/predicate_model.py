@@ -12,6 +12,7 @@ There is no CPU fallback: without the HIP library or a GPU, construction fails.
 """
 from __future__ import annotations
 
+import functools
 import warnings
 from typing import Dict, List, Optional, Sequence
 
@@ -19,7 +20,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import _lib, ops
+from . import _lib, ops, training
 from .config import ClipConfig, config_by_name
 from .masks import PackedMasks, unpack_to_device
 from .prob_dict import ProbDict
@@ -29,6 +30,16 @@ CROP_DTYPE = np.dtype([("frame_off", "<i8"), ("mask_a_off", "<i8"), ("mask_b_off
                        ("frame_h", "<i4"), ("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4"), ("mode", "<i4"),
                        ("reserved", "<i4")])
 assert CROP_DTYPE.itemsize == 56
+
+
+def _no_grad_unless_training(fn):
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        if self._grad_mode():
+            return fn(self, *args, **kwargs)
+        with torch.no_grad():
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 class _ParamTree(nn.Module):
@@ -119,6 +130,7 @@ class PredicateModel(nn.Module):
         for k, prefix in enumerate(TOWER_PREFIXES):
             self.add_module(prefix, _ParamTree(random_state_dict(self.cfg, seed * 1000 + k), self.device))
         self._towers = None          # packed device blobs, rebuilt when weights change
+        self._train_towers = None    # training-form towers over the fp32 parameters (built on first use)
         self._text_cache: Dict = {}
         self.cache_text_features = True
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed_weights())
@@ -137,6 +149,35 @@ class PredicateModel(nn.Module):
     def invalidate_packed_weights(self):
         self._towers = None
         self._text_cache = {}
+
+    def enable_training(self, on: bool = True):
+        """Make the CLIP parameters trainable (the reference's are by default, llava_clip_model_v3.py:19-21;
+        here they start frozen so that scoring never records activations).  With trainable parameters and
+        autograd enabled, forward() runs the training form of the towers and its outputs carry gradients;
+        under torch.no_grad() it stays the inference path, reading the current parameter values."""
+        self.requires_grad_(on)
+        return self
+
+    def _grad_mode(self) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def _trainers(self):
+        if self._train_towers is None:
+            tt = {}
+            for prefix in TOWER_PREFIXES:
+                params = dict(self._modules[prefix].named_parameters())
+                tt[prefix] = (training.TrainTower(self.cfg, "vision", params), training.TrainTower(self.cfg, "text", params),
+                              params["logit_scale"])
+            self._train_towers = tt
+        return self._train_towers
+
+    def _drop_stale_packed_weights(self):
+        """Called once per forward(): an optimizer step or an in-place edit of a parameter since the
+        blobs were packed bumps its version counter."""
+        versions = tuple(p._version for p in self.parameters())
+        if versions != getattr(self, "_packed_versions", None):
+            self.invalidate_packed_weights()
+            self._packed_versions = versions
 
     def _packed(self):
         if self._towers is None:
@@ -184,6 +225,10 @@ class PredicateModel(nn.Module):
         return DeviceInputs(frames, frame_off, frame_hw, masks, mask_off, mask_ndim)
 
     def _text_features(self, prefix: str, kws: Sequence[str]) -> torch.Tensor:
+        if self._grad_mode():
+            tokens = self.clip_tokenizer(list(kws), return_tensors="pt", max_length=75, truncation=True, padding="max_length")
+            am = tokens.get("attention_mask") if hasattr(tokens, "get") else tokens["attention_mask"]
+            return training.encode_text(self._trainers()[prefix][1], tokens["input_ids"], am)
         key = (prefix, tuple(kws))
         if self.cache_text_features and not self.training and key in self._text_cache:
             return self._text_cache[key]
@@ -200,8 +245,18 @@ class PredicateModel(nn.Module):
         return ops.crop_preprocess(dev_in.frames, dev_in.masks, table, cfg.image, layout=_lib.LAYOUT_PATCHES,
                                    patch=cfg.patch, out_dtype=_lib.DTYPE_BF16, alpha=alpha, white_alpha=white_alpha)
 
+    def _encode_images(self, prefix: str, patches: torch.Tensor, n: int) -> torch.Tensor:
+        if self._grad_mode():
+            return training.encode_images(self._trainers()[prefix][0], patches, n)
+        return self._packed()[prefix][0].encode_images(patches, n)
+
+    def _similarity(self, prefix: str, text: torch.Tensor, img: torch.Tensor, mode: int) -> torch.Tensor:
+        if self._grad_mode():
+            return training.similarity(text, img, self._trainers()[prefix][2], mode)
+        return ops.similarity(text, img, self._packed()[prefix][2], mode)
+
     # -- forward ---------------------------------------------------------------
-    @torch.no_grad()
+    @_no_grad_unless_training
     def forward(self, batched_video_ids, batched_videos, batched_masks, batched_bboxes, batched_names,
                 batched_object_ids, batched_unary_kws, batched_binary_kws, batched_obj_pairs, batched_video_splits,
                 batched_binary_predicates, unary_segment_size=None, binary_segment_size=None, alpha=0.5,
@@ -209,10 +264,14 @@ class PredicateModel(nn.Module):
                 output_embeddings=False, device_inputs: Optional[DeviceInputs] = None, allow_dummy_pair: bool = True):
         """Reference signature (llava_clip_model_v3.py:86-107) plus two optional extras: `device_inputs`
         (frames / masks already staged in HBM) and `allow_dummy_pair` (False: a call without any pair
-        scores no whole-frame stand-in, for shards of a larger call that does have pairs)."""
-        towers = self._packed()
+        scores no whole-frame stand-in, for shards of a larger call that does have pairs).
+        Gradients flow to the CLIP parameters when they are trainable (`enable_training`) and autograd
+        is enabled; otherwise the call runs under torch.no_grad()."""
         dev = self.device
         B = len(batched_video_ids)
+        grad_mode = self._grad_mode()
+        if not grad_mode:
+            self._drop_stale_packed_weights()
 
         def fill_empty(batched_kw):
             return [list(kw) if len(kw) else [dummy_str] for kw in batched_kw]
@@ -265,15 +324,15 @@ class PredicateModel(nn.Module):
                 if oid not in group_of:
                     group_of[oid] = len(oids)
                     oids.append(oid)
-            seg = torch.tensor([group_of[oid] for (_, oid) in ids_lookup[vid]], dtype=torch.int32).to(dev)
-            groups[vid] = (oids, seg)
+            seg_host = [group_of[oid] for (_, oid) in ids_lookup[vid]]
+            groups[vid] = (oids, torch.tensor(seg_host, dtype=torch.int32).to(dev), seg_host)
 
         # Step 3: object crops through the category and unary towers (:233-339)
         cate_feat = unary_feat = None
         if n_obj:
             patches = self._crops(di, obj_table, alpha, white_alpha)
-            cate_feat = towers["clip_cate_model"][0].encode_images(patches, n_obj)
-            unary_feat = towers["clip_unary_model"][0].encode_images(patches, n_obj)
+            cate_feat = self._encode_images("clip_cate_model", patches, n_obj)
+            unary_feat = self._encode_images("clip_unary_model", patches, n_obj)
         sim_mode = _lib.SIM_LOGIT if output_logit else _lib.SIM_SOFTMAX
 
         cate_out: Dict[int, object] = {v: {} for v in range(B)}
@@ -293,8 +352,8 @@ class PredicateModel(nn.Module):
             cate_feats_out[vid], unary_feats_out[vid] = cf, uf
             names, ukws = batched_names[vid], batched_unary_kws[vid]
             if e > s:
-                cate_dense = ops.similarity(name_feats[vid], cf, towers["clip_cate_model"][2], sim_mode)
-                unary_dense = ops.similarity(unary_feats[vid], uf, towers["clip_unary_model"][2], sim_mode)
+                cate_dense = self._similarity("clip_cate_model", name_feats[vid], cf, sim_mode)
+                unary_dense = self._similarity("clip_unary_model", unary_feats[vid], uf, sim_mode)
                 for r, nm in enumerate(names):
                     if nm == dummy_str:
                         dummy_terms.append(cate_dense[r].sum())
@@ -302,8 +361,11 @@ class PredicateModel(nn.Module):
                     if nm == dummy_str:
                         dummy_terms.append(unary_dense[r].sum())
                 # per-object mean over frames (:296-311); groups in order of first appearance
-                oids, seg = groups[vid]
-                cate_mean = ops.segment_mean(cate_dense, seg, len(oids))
+                oids, seg, seg_host = groups[vid]
+                if grad_mode:
+                    cate_mean = training.segment_mean(cate_dense, seg, len(oids), seg_host)
+                else:
+                    cate_mean = ops.segment_mean(cate_dense, seg, len(oids))
                 # a name listed twice pools both rows' probabilities into one mean in the reference (:296-311)
                 uniq: Dict[str, list] = {}
                 for r, nm in enumerate(names):
@@ -319,7 +381,7 @@ class PredicateModel(nn.Module):
                 unary_out[vid] = ProbDict(unary_dense, u_rows, list(enumerate(object_ids)),
                                           lambda fo, nm: (fo[0], fo[1], nm), "row_major")
                 if need_ranking:
-                    host = cate_mean.cpu()
+                    host = cate_mean.detach().cpu()
                     # per category: (prob, oid) sorted descending, ties by descending oid (:313-314)
                     obj_per_cate_all[vid] = {nm: sorted([(float(host[r, g]), oid) for g, oid in enumerate(oids)], reverse=True)
                                              for r, nm in c_rows}
@@ -385,7 +447,7 @@ class PredicateModel(nn.Module):
         pair_feat = None
         if n_pair:
             ppatches = self._crops(di, pair_table, alpha, white_alpha)
-            pair_feat = towers["clip_binary_model"][0].encode_images(ppatches, n_pair)
+            pair_feat = self._encode_images("clip_binary_model", ppatches, n_pair)
 
         binary_out: List[object] = []
         pair_feats_out: Dict[int, object] = {v: torch.tensor([]) for v in range(B)}
@@ -401,7 +463,7 @@ class PredicateModel(nn.Module):
             pf = pair_feat[s:e]
             pair_feats_out[vid] = pf
             bkws = batched_binary_kws[vid]
-            dense = ops.similarity(binary_feats[vid], pf, towers["clip_binary_model"][2], bmode)
+            dense = self._similarity("clip_binary_model", binary_feats[vid], pf, bmode)
             cols = []
             for c, (_, fid, pr) in enumerate(new_select[vid]):
                 if fid == -1:

@@ -29,18 +29,29 @@ class OraclePredicateModel:
         self.tok = tokenizer
         self.S = image_size or cfg.image
         self.timers: Dict[str, float] = {}
+        # True: the returned values stay attached to the autograd graph of the state-dict tensors
+        # (fp32 autograd reference for the train step, scripts/train_sgclip.py:682-694, 877-890)
+        self.grad = False
 
     # ----- helpers ---------------------------------------------------------
     def _text(self, sd, kws):
         t = self.tok(list(kws), return_tensors="pt", max_length=75, truncation=True, padding="max_length")
-        return clip_ref.text_features(sd, self.cfg, t["input_ids"], t.get("attention_mask"))
+        fn = clip_ref.text_features.__wrapped__ if self.grad else clip_ref.text_features
+        return fn(sd, self.cfg, t["input_ids"], t.get("attention_mask"))
+
+    def _image(self, sd, px):
+        fn = clip_ref.image_features.__wrapped__ if self.grad else clip_ref.image_features
+        return fn(sd, self.cfg, px)
 
     def _pixels(self, crops: List[np.ndarray]) -> torch.Tensor:
         return torch.from_numpy(np.stack([resample_ref.preprocess(c, self.S) for c in crops]))
 
     # ----- forward ---------------------------------------------------------
-    @torch.no_grad()
-    def forward(self, batched_video_ids, batched_videos, batched_masks, batched_bboxes, batched_names,
+    def forward(self, *args, **kwargs):
+        with torch.set_grad_enabled(self.grad):
+            return self._forward(*args, **kwargs)
+
+    def _forward(self, batched_video_ids, batched_videos, batched_masks, batched_bboxes, batched_names,
                 batched_object_ids, batched_unary_kws, batched_binary_kws, batched_obj_pairs,
                 batched_video_splits, batched_binary_predicates, unary_segment_size=None,
                 binary_segment_size=None, alpha=0.5, white_alpha=0.8, topk_cate=3, dummy_str="$$$",
@@ -87,8 +98,8 @@ class OraclePredicateModel:
                 px = self._pixels(crops)
                 self.timers["obj_pre"] += time.perf_counter() - t0
                 t0 = time.perf_counter()
-                cf = clip_ref.image_features(self.cate, self.cfg, px)
-                uf = clip_ref.image_features(self.unary, self.cfg, px)
+                cf = self._image(self.cate, px)
+                uf = self._image(self.unary, px)
                 self.timers["obj_encode"] += time.perf_counter() - t0
             else:
                 cf = uf = torch.tensor([])
@@ -179,7 +190,7 @@ class OraclePredicateModel:
             px = self._pixels(crops)
             self.timers["pair_pre"] += time.perf_counter() - t0
             t0 = time.perf_counter()
-            pf = clip_ref.image_features(self.binary, self.cfg, px)
+            pf = self._image(self.binary, px)
             self.timers["pair_encode"] += time.perf_counter() - t0
             pair_feats_out[vid] = pf
             bl = clip_ref.clip_sim(binary_feats[vid], pf, self.binary["logit_scale"])

@@ -185,3 +185,40 @@ def test_frame_shard_plan_covers_every_crop_once():
         for r in range(world):                      # a pair lives with both of its objects
             frames = {kw["batched_object_ids"][i][:2] for i in plan.obj_pos[r]}
             assert all(kw["batched_obj_pairs"][i][:2] in frames for i in plan.pair_pos[r])
+
+
+def _grad_worker(rank, world, port, q):
+    from laser_amd.training import allreduce_gradients
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 300, 1, 64)]
+        params.append(torch.nn.Parameter(torch.zeros(7), requires_grad=False))
+        for i, p in enumerate(params[:4]):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        if rank == 1:
+            params[2].grad = None        # a parameter this rank's batch never touched
+        allreduce_gradients(params, bucket_bytes=1024)     # several buckets
+        want = [(1 + 2) / 2 * (i + 1) for i in range(4)]
+        want[2] = 1 * 3 / 2
+        ok = all(torch.allclose(p.grad, torch.full_like(p, w)) for p, w in zip(params[:4], want))
+        ok = ok and params[4].grad is None
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_gradients_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]

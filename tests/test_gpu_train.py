@@ -1,0 +1,130 @@
+"""GPU tests of the train step through PredicateModel.forward(): probabilities and parameter
+gradients against fp32 autograd of the CPU oracle on the same inputs, and an optimisation run."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from laser_amd import training  # noqa: E402
+from laser_amd.config import config_by_name  # noqa: E402
+from laser_amd.predicate_model import PredicateModel  # noqa: E402
+from laser_amd.synthetic import make_clip_batch  # noqa: E402
+from laser_amd.tokenizer import HashTokenizer  # noqa: E402
+from laser_amd.weights import TOWER_PREFIXES, predicate_model_state_dict, split_predicate_state_dict  # noqa: E402
+
+
+def _setup(seed, logit_scale):
+    cfg = config_by_name("tiny")
+    sd = predicate_model_state_dict(cfg, seed, logit_scale)
+    tok = HashTokenizer(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    model = PredicateModel(None, None, "cuda:0", "tiny", tokenizer=tok)
+    model.load_state_dict(sd)
+    return cfg, sd, tok, model
+
+
+def _loss(out, weights_seed):
+    """A fixed random linear functional of every returned probability (same key order on both sides)."""
+    vals = []
+    for v in sorted(out[0]):
+        for d in (out[0][v], out[1][v]):
+            if len(d):
+                vals.append(d.values_tensor() if hasattr(d, "values_tensor") else torch.stack(list(d.values())))
+    for d in out[2]:
+        if len(d):
+            vals.append(d.values_tensor() if hasattr(d, "values_tensor") else torch.stack(list(d.values())))
+    flat = torch.cat([v.reshape(-1) for v in vals])
+    w = torch.from_numpy(np.random.default_rng(weights_seed).standard_normal(flat.numel()).astype(np.float32))
+    return (flat * w.to(flat.device)).sum() + 0.3 * out[3].to(flat.device), flat
+
+
+def test_forward_with_gradients_matches_fp32_autograd_of_the_oracle():
+    from oracle.forward_ref import OraclePredicateModel
+    cfg, sd, tok, model = _setup(21, float(np.log(8.0)))
+    b = make_clip_batch(9, n_videos=2, frames=3, objects=3, H=96, W=128, k_cate=5, k_unary=6, k_binary=4, min_box=12,
+                        max_box=90)
+    kw = b.forward_kwargs()
+    kw["batched_unary_kws"] = [list(kw["batched_unary_kws"][0]), []]        # a dummy keyword row in video 1
+    model.enable_training()
+    out = model(**kw)
+    loss, flat = _loss(out, 1)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    towers = {p: {k: (v.clone().float().requires_grad_(True) if v.is_floating_point() else v) for k, v in t.items()}
+              for p, t in split_predicate_state_dict(sd).items()}
+    oracle = OraclePredicateModel(cfg, towers, tok)
+    oracle.grad = True
+    torch.set_num_threads(16)
+    want = oracle(**kw)
+    wloss, wflat = _loss(want, 1)
+    wloss.backward()
+
+    assert [list(out[0][v].keys()) for v in out[0]] == [list(want[0][v].keys()) for v in want[0]]
+    assert (flat.detach().cpu() - wflat.detach()).abs().max().item() <= 2e-2
+    assert abs(loss.item() - wloss.item()) <= 5e-2 * max(1.0, abs(wloss.item()))
+    named = dict(model.named_parameters())
+    got_all, want_all, bad = [], [], {}
+    for prefix in TOWER_PREFIXES:
+        for k, ref in towers[prefix].items():
+            if not ref.is_floating_point():
+                continue
+            g = named[f"{prefix}.{k}"].grad
+            assert g is not None, (prefix, k)
+            g, r = g.detach().cpu().reshape(-1), (ref.grad if ref.grad is not None else torch.zeros_like(ref)).reshape(-1)
+            got_all.append(g)
+            want_all.append(r)
+            if "k_proj.bias" in k:        # exact gradient is zero (softmax shift invariance)
+                continue
+            rel = ((g - r).norm() / r.norm().clamp_min(1e-12)).item()
+            if rel > 0.1:
+                bad[f"{prefix}.{k}"] = rel
+    assert not bad, bad
+    g, r = torch.cat(got_all), torch.cat(want_all)
+    total = ((g - r).norm() / r.norm()).item()
+    assert total <= 5e-2, total
+    print(f"train forward: max |p - oracle| = {(flat.detach().cpu() - wflat.detach()).abs().max().item():.2e}, "
+          f"all-parameter gradient rel. error {total:.2e}")
+
+
+def test_inference_after_a_step_reads_the_updated_weights_and_matches_the_training_forward():
+    cfg, sd, tok, model = _setup(22, float(np.log(20.0)))
+    b = make_clip_batch(10, n_videos=1, frames=2, objects=3, H=96, W=128, k_cate=4, k_unary=5, k_binary=3, min_box=12,
+                        max_box=90)
+    kw = b.forward_kwargs()
+    with torch.no_grad():
+        before = model(**kw)[1][0].values_tensor().clone()
+    model.enable_training()
+    opt = training.Adam(model.parameters(), lr=1e-3)
+    out = model(**kw)
+    assert out[1][0].dense.requires_grad
+    (-torch.log(out[1][0].values_tensor()[0])).backward()
+    opt.step()
+    opt.zero_grad()
+    train_view = model(**kw)[1][0].values_tensor().detach()
+    with torch.no_grad():
+        after = model(**kw)[1][0].values_tensor()
+    torch.cuda.synchronize()
+    assert (after - before).abs().max().item() > 1e-4           # the step changed the scores
+    assert (after - train_view).abs().max().item() <= 2e-2      # both forms of the forward agree
+
+
+def test_a_few_adam_steps_raise_the_target_probabilities():
+    cfg, sd, tok, model = _setup(23, float(np.log(20.0)))
+    b = make_clip_batch(11, n_videos=1, frames=2, objects=4, H=96, W=128, k_cate=4, k_unary=6, k_binary=4, min_box=12,
+                        max_box=90)
+    kw = b.forward_kwargs()
+    model.enable_training()
+    opt = training.Adam(model.parameters(), lr=2e-4)
+    losses = []
+    for _ in range(6):
+        cate, unary, binary, dummy = model(**kw)
+        # push the first keyword of every vocabulary up for every crop
+        u, bn = unary[0].dense[0], binary[0].dense[0]
+        c = cate[0].dense[0]
+        loss = -(torch.log(u + 1e-6).mean() + torch.log(bn + 1e-6).mean() + torch.log(c + 1e-6).mean()) + 0.0 * dummy
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] * 0.8, losses
