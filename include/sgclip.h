@@ -215,6 +215,8 @@ int sgclip_mask_unpack(const uint8_t *packed_dev, size_t packed_bytes, const sgc
 #define SGCLIP_EPI_BIAS_RESID_F32 2 /* C_f32 += A W^T + bias (in place)        */
 #define SGCLIP_EPI_PATCH_F32 3      /* C_f32[(m/P)*T + 1 + m%P] = A W^T + aux[(1 + m%P)]  (aux = pos emb, P = aux_rows) */
 #define SGCLIP_EPI_F32 4            /* C_f32 = A W^T                           */
+#define SGCLIP_EPI_F32_ATOMIC 5     /* C_f32 += A W^T, the K range split over several workgroups that add their
+                                     * partial tiles with fp32 atomics (weight gradients: few tiles, very long K) */
 /* A: bf16 [M, K] (lda), W: bf16 [N, K] (ldw), C: [.., N] (ldc); K % 64 == 0.  */
 int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, int ldw, void *C_dev, int ldc, int M, int N,
                      int K, int epilogue, const float *bias_dev, const float *aux_dev, int aux_rows,
@@ -268,6 +270,8 @@ int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, void *dqkv_d
  * For the small fp32 tail (projection, similarity) where bf16 would cost accuracy. */
 int sgclip_matmul_f32(const float *A_dev, int64_t lda, int transA, const float *B_dev, int64_t ldb, int transB,
                       float *C_dev, int64_t ldc, int M, int N, int K, float alpha, int accumulate, void *stream);
+/* *out += <a, b> over n fp32 elements (caller zeroes out). */
+int sgclip_dot_f32(const float *a_dev, const float *b_dev, int64_t n, float *out_dev, void *stream);
 /* dlogits [K][N] from dprobs: softmax over k per column n, sigmoid, or copy (mode = SGCLIP_SIM_*). */
 int sgclip_prob_bwd(const float *probs_dev, const float *dprobs_dev, int K, int N, int mode, float *dlogits_dev,
                     void *stream);

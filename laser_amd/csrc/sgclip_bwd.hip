@@ -27,6 +27,39 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t *__res
     }
 }
 
+// The same transpose with 16-byte global accesses: cols, ld_in, ld_out multiples of 8 and both
+// pointers 16-byte aligned.  LDS row stride 66 elements (33 words): the 8 x 8 (row chunk, column)
+// pattern of the read-back falls on 32 distinct banks.
+__global__ __launch_bounds__(256) void transpose_bf16_vec_kernel(const bf16_t *__restrict__ in, long long ld_in, int rows,
+                                                                 int cols, bf16_t *__restrict__ out, long long ld_out) {
+    __shared__ unsigned int tile[64 * 33];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int idx = threadIdx.x + 256 * i;  // 64 rows x 8 chunks of 8 columns
+        const int r = idx >> 3, ch = idx & 7;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r0 + r < rows && c0 + ch * 8 < cols) v = *(const uint4 *)(in + (size_t)(r0 + r) * ld_in + c0 + ch * 8);
+        unsigned int *dst = tile + r * 33 + ch * 4;
+        dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+    }
+    __syncthreads();
+    const unsigned short *t16 = (const unsigned short *)tile;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int idx = threadIdx.x + 256 * i;  // 64 columns x 8 chunks of 8 rows
+        const int c = idx >> 3, rc = idx & 7;
+        if (c0 + c >= cols || r0 + rc * 8 >= ld_out) continue;
+        unsigned int w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned int lo = t16[(rc * 8 + 2 * j) * 66 + c], hi = t16[(rc * 8 + 2 * j + 1) * 66 + c];
+            w[j] = lo | (hi << 16);
+        }
+        *(uint4 *)(out + (size_t)(c0 + c) * ld_out + r0 + rc * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // out[n] += sum over a slice of rows of in[m][n]
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ in, long long ld, int M, int N,
@@ -45,21 +78,46 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ in, l
 
 __device__ __forceinline__ float sigmoid1702(float x) { return 1.0f / (1.0f + __expf(-1.702f * x)); }
 
+// eight elements per thread (16-byte accesses; torch allocations are 16-byte aligned), scalar tail
 __global__ void quick_gelu_kernel(const bf16_t *__restrict__ u, bf16_t *__restrict__ g, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const float x = (float)u[i];
-        g[i] = (bf16_t)(x * sigmoid1702(x));
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const bf16x8 x = *(const bf16x8 *)(u + i);
+        bf16x8 y;
+#pragma unroll
+        for (int q = 0; q < 8; q++) y[q] = (bf16_t)((float)x[q] * sigmoid1702((float)x[q]));
+        *(bf16x8 *)(g + i) = y;
+    } else {
+        for (long long j = i; j < n; j++) g[j] = (bf16_t)((float)u[j] * sigmoid1702((float)u[j]));
     }
+}
+
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+    const float s = sigmoid1702(x);
+    return s + 1.702f * x * s * (1.0f - s);
 }
 
 __global__ void quick_gelu_bwd_kernel(const bf16_t *__restrict__ u, const bf16_t *__restrict__ dg, bf16_t *__restrict__ du,
                                       long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const float x = (float)u[i], s = sigmoid1702(x);
-        du[i] = (bf16_t)((float)dg[i] * (s + 1.702f * x * s * (1.0f - s)));
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const bf16x8 x = *(const bf16x8 *)(u + i), d = *(const bf16x8 *)(dg + i);
+        bf16x8 y;
+#pragma unroll
+        for (int q = 0; q < 8; q++) y[q] = (bf16_t)((float)d[q] * quick_gelu_grad((float)x[q]));
+        *(bf16x8 *)(du + i) = y;
+    } else {
+        for (long long j = i; j < n; j++) du[j] = (bf16_t)((float)dg[j] * quick_gelu_grad((float)u[j]));
     }
+}
+
+// out += <a, b>
+__global__ __launch_bounds__(256) void dot_f32_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n,
+                                                      float *__restrict__ out) {
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += a[i] * b[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
 __global__ void cast_f32_bf16_kernel(const float *__restrict__ in, bf16_t *__restrict__ out, long long n) {
@@ -68,53 +126,85 @@ __global__ void cast_f32_bf16_kernel(const float *__restrict__ in, bf16_t *__res
 }
 
 // ---------------------------------------------------------------------------
-// LayerNorm backward: one wave per row (statistics recomputed from x), dx per row,
-// dw / db reduced over the block's four rows in LDS, then one atomic per column and block.
+// LayerNorm backward: one wave per row, the row held in registers (NV values per lane, d <= 64 NV);
+// each wave walks rpw rows and keeps its dw / db partial sums in registers, the block's four
+// waves are summed through LDS and added to dw / db with one atomic per column and block.
 //   xh = (x - mean) rstd;  g = dy w;  dx = rstd (g - mean(g) - xh mean(g xh))
 // ---------------------------------------------------------------------------
-template <bool DY_BF16>
+constexpr int LN_RPW_MAX = 16;  // rows per wave: fewer when the launch would not fill the chip
+
+template <int NV, bool DY_BF16>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ x, long long x_stride, int rows, int d,
                                                             const float *__restrict__ w, float eps, const void *dy_,
                                                             float *dx, int accumulate, float *__restrict__ dw,
-                                                            float *__restrict__ db) {
-    extern __shared__ float lds_acc[];  // [2][d]: dw, db partial sums of this block
-    const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 2 * d; i += 256) lds_acc[i] = 0.f;
-    __syncthreads();
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row < rows) {
+                                                            float *__restrict__ db, int rpw) {
+    __shared__ float red[4][2][NV * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float wv[NV], dwacc[NV], dbacc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int c = lane + 64 * j;
+        wv[j] = c < d ? w[c] : 0.f;
+        dwacc[j] = 0.f;
+        dbacc[j] = 0.f;
+    }
+    const int row0 = (blockIdx.x * 4 + wave) * rpw;
+    const float inv_d = 1.0f / d;
+    for (int r = 0; r < rpw; r++) {
+        const int row = row0 + r;
+        if (row >= rows) break;
         const float *xr = x + (size_t)row * x_stride;
+        float xv[NV], dyv[NV];
         float s = 0.f;
-        for (int i = lane; i < d; i += 64) s += xr[i];
-        const float mean = wave_sum(s) / d;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int c = lane + 64 * j;
+            xv[j] = c < d ? xr[c] : 0.f;
+            if (DY_BF16)
+                dyv[j] = c < d ? (float)((const bf16_t *)dy_)[(size_t)row * d + c] : 0.f;
+            else
+                dyv[j] = c < d ? ((const float *)dy_)[(size_t)row * d + c] : 0.f;
+            s += xv[j];
+        }
+        const float mean = wave_sum(s) * inv_d;
         float q = 0.f;
-        for (int i = lane; i < d; i += 64) {
-            const float a = xr[i] - mean;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const float a = (lane + 64 * j) < d ? xv[j] - mean : 0.f;
             q += a * a;
         }
-        const float rstd = rsqrtf(wave_sum(q) / d + eps);
+        const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
         float sg = 0.f, sgx = 0.f;
-        for (int i = lane; i < d; i += 64) {
-            const float dyv = DY_BF16 ? (float)((const bf16_t *)dy_)[(size_t)row * d + i] : ((const float *)dy_)[(size_t)row * d + i];
-            const float xh = (xr[i] - mean) * rstd, g = dyv * w[i];
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const float xh = (lane + 64 * j) < d ? (xv[j] - mean) * rstd : 0.f;
+            xv[j] = xh;
+            const float g = dyv[j] * wv[j];
             sg += g;
             sgx += g * xh;
-            atomicAdd(&lds_acc[i], dyv * xh);
-            atomicAdd(&lds_acc[d + i], dyv);
+            dwacc[j] += dyv[j] * xh;
+            dbacc[j] += dyv[j];
         }
-        const float mg = wave_sum(sg) / d, mgx = wave_sum(sgx) / d;
+        const float mg = wave_sum(sg) * inv_d, mgx = wave_sum(sgx) * inv_d;
         float *dxr = dx + (size_t)row * d;
-        for (int i = lane; i < d; i += 64) {
-            const float dyv = DY_BF16 ? (float)((const bf16_t *)dy_)[(size_t)row * d + i] : ((const float *)dy_)[(size_t)row * d + i];
-            const float xh = (xr[i] - mean) * rstd;
-            const float v = rstd * (dyv * w[i] - mg - xh * mgx);
-            dxr[i] = accumulate ? dxr[i] + v : v;
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const int c = lane + 64 * j;
+            if (c < d) {
+                const float v = rstd * (dyv[j] * wv[j] - mg - xv[j] * mgx);
+                dxr[c] = accumulate ? dxr[c] + v : v;
+            }
         }
     }
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        red[wave][0][lane + 64 * j] = dwacc[j];
+        red[wave][1][lane + 64 * j] = dbacc[j];
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < d; i += 256) {
-        atomicAdd(dw + i, lds_acc[i]);
-        atomicAdd(db + i, lds_acc[d + i]);
+    for (int c = threadIdx.x; c < d; c += 256) {
+        atomicAdd(dw + c, red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c]);
+        atomicAdd(db + c, red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c]);
     }
 }
 
@@ -370,6 +460,11 @@ extern "C" int sgclip_transpose_bf16(const void *in_dev, int64_t ld_in, int rows
     if (rows == 0 || cols == 0) return SGCLIP_OK;
     BWD_ARGS_OK(in_dev && out_dev && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= rows, "sgclip_transpose_bf16");
     const dim3 grid(ceil_div((int)ld_out, 64), ceil_div(cols, 64));
+    if (cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && !((uintptr_t)in_dev & 15) && !((uintptr_t)out_dev & 15)) {
+        hipLaunchKernelGGL(transpose_bf16_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)in_dev,
+                           (long long)ld_in, rows, cols, (bf16_t *)out_dev, (long long)ld_out);
+        return launch_check("sgclip_transpose_bf16");
+    }
     hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)in_dev,
                        (long long)ld_in, rows, cols, (bf16_t *)out_dev, (long long)ld_out);
     return launch_check("sgclip_transpose_bf16");
@@ -392,7 +487,8 @@ extern "C" int sgclip_colsum(const void *in_dev, int in_dtype, int64_t ld, int M
 extern "C" int sgclip_quick_gelu(const void *u_dev, void *g_dev, int64_t n, void *stream) {
     if (n == 0) return SGCLIP_OK;
     BWD_ARGS_OK(u_dev && g_dev && n > 0, "sgclip_quick_gelu");
-    hipLaunchKernelGGL(quick_gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    BWD_ARGS_OK(!((uintptr_t)u_dev & 15) && !((uintptr_t)g_dev & 15), "sgclip_quick_gelu (16-byte alignment)");
+    hipLaunchKernelGGL(quick_gelu_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t *)u_dev, (bf16_t *)g_dev, (long long)n);
     return launch_check("sgclip_quick_gelu");
 }
@@ -400,7 +496,9 @@ extern "C" int sgclip_quick_gelu(const void *u_dev, void *g_dev, int64_t n, void
 extern "C" int sgclip_quick_gelu_bwd(const void *u_dev, const void *dg_dev, void *du_dev, int64_t n, void *stream) {
     if (n == 0) return SGCLIP_OK;
     BWD_ARGS_OK(u_dev && dg_dev && du_dev && n > 0, "sgclip_quick_gelu_bwd");
-    hipLaunchKernelGGL(quick_gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    BWD_ARGS_OK(!((uintptr_t)u_dev & 15) && !((uintptr_t)dg_dev & 15) && !((uintptr_t)du_dev & 15),
+                "sgclip_quick_gelu_bwd (16-byte alignment)");
+    hipLaunchKernelGGL(quick_gelu_bwd_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t *)u_dev, (const bf16_t *)dg_dev, (bf16_t *)du_dev, (long long)n);
     return launch_check("sgclip_quick_gelu_bwd");
 }
@@ -419,14 +517,33 @@ extern "C" int sgclip_layernorm_bwd(const float *x_dev, int64_t x_stride, int ro
     if (rows == 0) return SGCLIP_OK;
     BWD_ARGS_OK(x_dev && w_dev && dy_dev && dx_dev && dw_dev && db_dev && rows > 0 && d > 0 && x_stride >= d,
                 "sgclip_layernorm_bwd");
-    const dim3 grid(ceil_div(rows, 4));
-    const size_t lds = (size_t)2 * d * sizeof(float);
-    if (dy_dtype == SGCLIP_DTYPE_BF16)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, x_dev, (long long)x_stride,
-                           rows, d, w_dev, eps, dy_dev, dx_dev, accumulate_dx, dw_dev, db_dev);
+    if (d > 1024) {
+        set_error("sgclip_layernorm_bwd: d=%d > 1024 is not supported", d);
+        return SGCLIP_EINVAL;
+    }
+    const int rpw = std::max(1, std::min(LN_RPW_MAX, rows / (4 * 2048)));
+    const dim3 grid(ceil_div(rows, 4 * rpw));
+    const bool bf = dy_dtype == SGCLIP_DTYPE_BF16;
+#define LN_BWD_LAUNCH(NV)                                                                                                  \
+    do {                                                                                                                   \
+        if (bf)                                                                                                            \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<NV, true>), grid, dim3(256), 0, (hipStream_t)stream, x_dev,          \
+                               (long long)x_stride, rows, d, w_dev, eps, dy_dev, dx_dev, accumulate_dx, dw_dev, db_dev,   \
+                               rpw);                                                                                       \
+        else                                                                                                               \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<NV, false>), grid, dim3(256), 0, (hipStream_t)stream, x_dev,         \
+                               (long long)x_stride, rows, d, w_dev, eps, dy_dev, dx_dev, accumulate_dx, dw_dev, db_dev,   \
+                               rpw);                                                                                       \
+    } while (0)
+    if (d <= 128)
+        LN_BWD_LAUNCH(2);
+    else if (d <= 512)
+        LN_BWD_LAUNCH(8);
+    else if (d <= 768)
+        LN_BWD_LAUNCH(12);
     else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, x_dev, (long long)x_stride,
-                           rows, d, w_dev, eps, dy_dev, dx_dev, accumulate_dx, dw_dev, db_dev);
+        LN_BWD_LAUNCH(16);
+#undef LN_BWD_LAUNCH
     return launch_check("sgclip_layernorm_bwd");
 }
 
@@ -456,6 +573,14 @@ extern "C" int sgclip_matmul_f32(const float *A_dev, int64_t lda, int transA, co
     hipLaunchKernelGGL(matmul_f32_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, (hipStream_t)stream, A_dev,
                        (long long)lda, transA, B_dev, (long long)ldb, transB, C_dev, (long long)ldc, M, N, K, alpha, accumulate);
     return launch_check("sgclip_matmul_f32");
+}
+
+extern "C" int sgclip_dot_f32(const float *a_dev, const float *b_dev, int64_t n, float *out_dev, void *stream) {
+    if (n == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(a_dev && b_dev && out_dev && n > 0, "sgclip_dot_f32");
+    const unsigned blocks = (unsigned)std::min<int64_t>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(dot_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a_dev, b_dev, (long long)n, out_dev);
+    return launch_check("sgclip_dot_f32");
 }
 
 extern "C" int sgclip_prob_bwd(const float *probs_dev, const float *dprobs_dev, int K, int N, int mode, float *dlogits_dev,

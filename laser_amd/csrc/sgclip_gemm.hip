@@ -21,6 +21,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace sgclip {
 
 constexpr int BN = 128, BK = 64;
@@ -32,7 +34,8 @@ struct GemmArgs {
     const float *bias;
     const float *aux;
     int lda, ldw, ldc;
-    int M, N, K;
+    int M, N, K;        // K: depth one workgroup walks (the whole K unless the launch splits it over blockIdx.y)
+    int k_total;
     int aux_rows;
     int tiles_m, tiles_n;
     int wide_epilogue;  // N % 8 == 0, ldc % 8 == 0 and C, bias, aux 16-byte aligned
@@ -63,6 +66,21 @@ __device__ __forceinline__ float quick_gelu(float x) {
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// split-K launches: workgroup row blockIdx.y owns K range [y * g.K, min((y + 1) * g.K, k_total))
+__device__ __forceinline__ void split_k_setup(GemmArgs &g) {
+    const int k0 = blockIdx.y * g.K;
+    g.A += k0;
+    g.W += k0;
+    g.K = min(g.K, g.k_total - k0);
+}
+
+__device__ __forceinline__ void atomic_add4(float *p, float a, float b, float c, float d) {
+    unsafeAtomicAdd(p, a);
+    unsafeAtomicAdd(p + 1, b);
+    unsafeAtomicAdd(p + 2, c);
+    unsafeAtomicAdd(p + 3, d);
 }
 
 // one 64-deep K step of a wave's 64 x 64 sub-tile
@@ -112,6 +130,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, const f32x4 (&acc)[4
                     const int img = m / P, pp = m - img * P;
                     const size_t row = (size_t)img * (P + 1) + 1 + pp;
                     ((float *)g.C)[row * g.ldc + n] = v + g.aux[(size_t)(1 + pp) * g.ldc + n];
+                } else if (EPI == SGCLIP_EPI_F32_ATOMIC) {
+                    unsafeAtomicAdd((float *)g.C + (size_t)m * g.ldc + n, v);
                 } else {
                     ((float *)g.C)[(size_t)m * g.ldc + n] = v;
                 }
@@ -168,6 +188,8 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs &g, const f32x4 (&ac
             const size_t orow = (size_t)img * (P + 1) + 1 + pp;
             const float4 a = *(const float4 *)(g.aux + (size_t)(1 + pp) * g.ldc + n);
             *(float4 *)((float *)g.C + orow * g.ldc + n) = make_float4(v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+        } else if (EPI == SGCLIP_EPI_F32_ATOMIC) {
+            atomic_add4((float *)g.C + (size_t)m * g.ldc + n, v.x, v.y, v.z, v.w);
         } else {
             *(float4 *)((float *)g.C + (size_t)m * g.ldc + n) = v;
         }
@@ -181,6 +203,7 @@ template <int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     constexpr int TILE = 128 * 128;  // bytes per operand tile
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * TILE];  // A0 B0 A1 B1
+    split_k_setup(g);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int swz = xcd_remap(blockIdx.x, gridDim.x);
@@ -225,6 +248,7 @@ constexpr int RING_PW = (RING_SLOT / 1024) / 8;  // DMA instructions per wave pe
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    split_k_setup(g);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -374,6 +398,8 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
                 const size_t orow = (size_t)img * (P + 1) + 1 + pp;
                 const float4 a = *(const float4 *)(g.aux + (size_t)(1 + pp) * g.ldc + n);
                 *(float4 *)((float *)g.C + orow * g.ldc + n) = make_float4(v[0] + a.x, v[1] + a.y, v[2] + a.z, v[3] + a.w);
+            } else if constexpr (EPI == SGCLIP_EPI_F32_ATOMIC) {
+                atomic_add4((float *)g.C + (size_t)m * g.ldc + n, v[0], v[1], v[2], v[3]);
             } else {
                 *(float4 *)((float *)g.C + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -385,6 +411,7 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
 template <int EPI>
 __global__ __launch_bounds__(512, 4) void gemm_ring32_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    split_k_setup(g);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -458,6 +485,7 @@ constexpr int BIG_PW = (BIG_SLOT / 1024) / 8;  // 4 DMA instructions per wave pe
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    split_k_setup(g);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 rows x 128 columns
@@ -544,13 +572,14 @@ static int gemm_variant() {
 }
 
 template <int EPI>
-static void launch(const GemmArgs &g0, hipStream_t stream) {
+static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
     GemmArgs g = g0;
+    const unsigned gy = (unsigned)splits;
     // measured on MI355X (M = 65536, random data): the 32-deep two-workgroups-per-CU kernel wins
     // for short K (epilogue-heavy), the 64-deep ring for long K
     const int variant = gemm_variant();
     const bool use32 = variant == 2 || (variant >= 3 && g.K <= 1024);
-    const long big_tiles = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256);
+    const long big_tiles = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) * splits;
     if ((variant == 4 || (variant == 5 && big_tiles >= 512)) && g.M > 128 && g.K % 32 == 0 && g.N >= 256) {
         g.tiles_m = ceil_div(g.M, 256);
         g.tiles_n = ceil_div(g.N, 256);
@@ -560,7 +589,7 @@ static void launch(const GemmArgs &g0, hipStream_t stream) {
                                       BIG_SLOTS * BIG_SLOT);
             attr_big = true;
         }
-        hipLaunchKernelGGL(gemm_big_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n), dim3(512), BIG_SLOTS * BIG_SLOT,
+        hipLaunchKernelGGL(gemm_big_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n, gy), dim3(512), BIG_SLOTS * BIG_SLOT,
                            stream, g);
     } else if (use32 && g.M > 128 && g.K % 32 == 0) {
         g.tiles_m = ceil_div(g.M, RING_BM);
@@ -570,7 +599,7 @@ static void launch(const GemmArgs &g0, hipStream_t stream) {
                                       R32_SLOTS * R32_SLOT);
             attr_set32 = true;
         }
-        hipLaunchKernelGGL(gemm_ring32_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n), dim3(512), R32_SLOTS * R32_SLOT,
+        hipLaunchKernelGGL(gemm_ring32_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n, gy), dim3(512), R32_SLOTS * R32_SLOT,
                            stream, g);
     } else if (gemm_variant() >= 1 && g.M > 128) {
         g.tiles_m = ceil_div(g.M, RING_BM);
@@ -580,11 +609,11 @@ static void launch(const GemmArgs &g0, hipStream_t stream) {
                                       RING_SLOTS * RING_SLOT);
             attr_set = true;
         }
-        hipLaunchKernelGGL(gemm_ring_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n), dim3(512), RING_SLOTS * RING_SLOT,
+        hipLaunchKernelGGL(gemm_ring_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n, gy), dim3(512), RING_SLOTS * RING_SLOT,
                            stream, g);
     } else {
         g.tiles_m = ceil_div(g.M, 128);
-        hipLaunchKernelGGL(gemm_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n), dim3(256), 0, stream, g);
+        hipLaunchKernelGGL(gemm_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n, gy), dim3(256), 0, stream, g);
     }
 }
 
@@ -624,6 +653,7 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
     g.M = M;
     g.N = N;
     g.K = K;
+    g.k_total = K;
     g.aux_rows = aux_rows;
     g.tiles_m = 0;
     g.tiles_n = ceil_div(N, BN);
@@ -644,6 +674,22 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
         case SGCLIP_EPI_BIAS_RESID_F32: launch<SGCLIP_EPI_BIAS_RESID_F32>(g, stream); break;
         case SGCLIP_EPI_PATCH_F32: launch<SGCLIP_EPI_PATCH_F32>(g, stream); break;
         case SGCLIP_EPI_F32: launch<SGCLIP_EPI_F32>(g, stream); break;
+        case SGCLIP_EPI_F32_ATOMIC: {
+            // K slices: about `target` workgroups in flight, each at least 512 deep.  More slices fill more CUs but every
+            // slice adds a full tile of fp32 atomics; 2-3 slices of the towers' weight gradients measured fastest
+            static int target = -1;
+            if (target < 0) {
+                const char *e = getenv("SGCLIP_SPLITK_WGS");
+                target = e ? atoi(e) : 96;
+            }
+            const long tiles = (long)ceil_div(M, 256) * ceil_div(N, N >= 256 ? 256 : BN);
+            int splits = (int)std::max(1L, std::min((long)ceil_div(K, 512), target / tiles));
+            const int kc = ceil_div(ceil_div(K, splits), BK) * BK;
+            splits = ceil_div(K, kc);
+            g.K = kc;
+            launch<SGCLIP_EPI_F32_ATOMIC>(g, stream, splits);
+            break;
+        }
         default: set_error("sgclip_gemm_bf16: unknown epilogue %d", epilogue); return SGCLIP_EINVAL;
     }
     return launch_check("sgclip_gemm_bf16");

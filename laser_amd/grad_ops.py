@@ -109,6 +109,14 @@ def matmul_f32(A: torch.Tensor, B: torch.Tensor, transA: bool = False, transB: b
     return out
 
 
+def dot_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """0-dim f32 <a, b>."""
+    assert a.dtype == F32 and b.dtype == F32 and a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    out = torch.zeros((), dtype=F32, device=a.device)
+    _lib.check(_lib.load().sgclip_dot_f32(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), _stream()))
+    return out
+
+
 def prob_bwd(probs: torch.Tensor, dprobs: torch.Tensor, mode: int) -> torch.Tensor:
     assert probs.dtype == F32 and probs.is_contiguous() and dprobs.is_contiguous() and probs.shape == dprobs.shape
     K, N = probs.shape
@@ -181,11 +189,15 @@ def linear_dgrad(dy: torch.Tensor, w_t: torch.Tensor, zero_bias: torch.Tensor) -
     return gemm_bf16(dy, w_t, dx, _lib.EPI_BIAS_BF16, bias=zero_bias)
 
 
-def linear_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW f32 [out, in] = dy^T x for dy bf16 [M, out], x bf16 [M, in]; M is zero-padded to a multiple of 64."""
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out f32 [out, in] += dy^T x for dy bf16 [M, out], x bf16 [M, in] (out: zeros when omitted); M is zero-padded
+    to a multiple of 64.  The reduction over M (all tokens of the batch) is split over workgroups that add into
+    `out` atomically, so repeated calls accumulate."""
     M = dy.shape[0]
     Mp = pad64(M)
     dyt = transpose_bf16(dy, Mp)
     xt = transpose_bf16(x, Mp)
-    dw = torch.empty((dy.shape[1], x.shape[1]), dtype=F32, device=dy.device)
-    return gemm_bf16(dyt, xt, dw, _lib.EPI_F32)
+    if out is None:
+        out = torch.zeros((dy.shape[1], x.shape[1]), dtype=F32, device=dy.device)
+    assert out.dtype == F32 and out.shape == (dy.shape[1], x.shape[1]) and out.stride(1) == 1
+    return gemm_bf16(dyt, xt, out, _lib.EPI_F32_ATOMIC)

@@ -158,6 +158,32 @@ class PredicateModel(nn.Module):
         self.requires_grad_(on)
         return self
 
+    def flatten_parameters(self) -> "training.FlatParameters":
+        """Move every parameter (and its gradient) into one fp32 buffer each, see `training.FlatParameters`:
+        weight gradients are accumulated in place, `training.Adam(flat)` is one launch, and
+        `training.allreduce_gradients(flat)` needs no packing.  Returns the (cached) FlatParameters."""
+        if getattr(self, "_flat", None) is None:
+            tt = self._trainers()
+            named = dict(self.named_parameters())
+            order: List[str] = []
+            for prefix in TOWER_PREFIXES:
+                for tower in tt[prefix][:2]:
+                    order += [f"{prefix}.{n}" for n in tower.names]
+                order.append(f"{prefix}.logit_scale")
+            order += [n for n in named if n not in set(order)]
+            self._flat = training.FlatParameters([(n, named[n]) for n in order])
+            for prefix in TOWER_PREFIXES:
+                for tower in tt[prefix][:2]:
+                    tower.flat, tower.flat_prefix = self._flat, prefix + "."
+            self.invalidate_packed_weights()
+        return self._flat
+
+    def set_recompute_chunk(self, images: Optional[int]):
+        """Bound the activation memory of the train step: the image towers keep no activations and recompute
+        their forward, `images` crops at a time, during backward (None: keep everything, no recompute)."""
+        for prefix in TOWER_PREFIXES:
+            self._trainers()[prefix][0].recompute_chunk = images
+
     def _grad_mode(self) -> bool:
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 

@@ -56,8 +56,8 @@ class TrainTower:
         for i in range(self.L):
             b = f"{self.pre}.encoder.layers.{i}"
             names += [f"{b}.layer_norm1.weight", f"{b}.layer_norm1.bias"]
-            for n in "qkv":
-                names += [f"{b}.self_attn.{n}_proj.weight", f"{b}.self_attn.{n}_proj.bias"]
+            names += [f"{b}.self_attn.{n}_proj.weight" for n in "qkv"]      # adjacent: one [3d, d] view when flat
+            names += [f"{b}.self_attn.{n}_proj.bias" for n in "qkv"]
             names += [f"{b}.self_attn.out_proj.weight", f"{b}.self_attn.out_proj.bias", f"{b}.layer_norm2.weight",
                       f"{b}.layer_norm2.bias", f"{b}.mlp.fc1.weight", f"{b}.mlp.fc1.bias", f"{b}.mlp.fc2.weight",
                       f"{b}.mlp.fc2.bias"]
@@ -67,6 +67,9 @@ class TrainTower:
         self._versions = None
         self._w: Dict[str, torch.Tensor] = {}
         self._zero_bias = torch.zeros(max(3 * self.d, self.ffn), dtype=F32, device=self.device)
+        self.flat: Optional["FlatParameters"] = None   # set by FlatParameters.attach
+        self.flat_prefix = ""
+        self.recompute_chunk: Optional[int] = None      # images per recomputed chunk (None: keep all activations)
 
     def param_list(self) -> List[nn.Parameter]:
         return [self.params[n] for n in self.names]
@@ -116,48 +119,40 @@ class TrainTower:
         ops.gemm_bf16(g, w[f"{i}.fc2"], x_out, _lib.EPI_BIAS_RESID_F32, bias=self._p(f"{b}.mlp.fc2.bias"))
         return x_out, (x, qkv, a, x_mid, u)
 
-    def _layer_backward(self, i, saved, dx, n_seq, T, causal, km, grads):
-        """dx: f32 [M, d] gradient of the layer's output, overwritten with that of its input."""
+    def _layer_backward(self, i, saved, dx, n_seq, T, causal, km, sink: "GradSink"):
+        """dx: f32 [M, d] gradient of the layer's output, overwritten with that of its input.
+        Parameter gradients are ADDED to the sink's tensors."""
         b, w, d = f"{self.pre}.encoder.layers.{i}", self._w, self.d
         x, qkv, a, x_mid, u = saved
         zb = self._zero_bias
-
-        def ln_grads(name):
-            dw = torch.zeros(d, dtype=F32, device=dx.device)
-            db = torch.zeros(d, dtype=F32, device=dx.device)
-            grads[f"{b}.{name}.weight"], grads[f"{b}.{name}.bias"] = dw, db
-            return dw, db
-
         # MLP
         dxb = G.cast_bf16(dx)
         g = G.quick_gelu(u)
-        grads[f"{b}.mlp.fc2.weight"] = G.linear_wgrad(dxb, g)
-        grads[f"{b}.mlp.fc2.bias"] = G.colsum(dx)
+        G.linear_wgrad(dxb, g, sink.get(f"{b}.mlp.fc2.weight"))
+        G.colsum(dx, sink.get(f"{b}.mlp.fc2.bias"))
         dg = G.linear_dgrad(dxb, w[f"{i}.fc2_t"], zb)
         du = G.quick_gelu_bwd(u, dg)
         del g, dg
         h2 = ops.layernorm(x_mid, self._p(f"{b}.layer_norm2.weight"), self._p(f"{b}.layer_norm2.bias"), self.eps)
-        grads[f"{b}.mlp.fc1.weight"] = G.linear_wgrad(du, h2)
-        grads[f"{b}.mlp.fc1.bias"] = G.colsum(du)
+        G.linear_wgrad(du, h2, sink.get(f"{b}.mlp.fc1.weight"))
+        G.colsum(du, sink.get(f"{b}.mlp.fc1.bias"))
         dh2 = G.linear_dgrad(du, w[f"{i}.fc1_t"], zb)
-        dw, db = ln_grads("layer_norm2")
-        G.layernorm_bwd(x_mid, self._p(f"{b}.layer_norm2.weight"), self.eps, dh2, dw, db, dx=dx, accumulate=True)
+        G.layernorm_bwd(x_mid, self._p(f"{b}.layer_norm2.weight"), self.eps, dh2, sink.get(f"{b}.layer_norm2.weight"),
+                        sink.get(f"{b}.layer_norm2.bias"), dx=dx, accumulate=True)
         del du, h2, dh2
         # attention
         dxb = G.cast_bf16(dx)
-        grads[f"{b}.self_attn.out_proj.weight"] = G.linear_wgrad(dxb, a)
-        grads[f"{b}.self_attn.out_proj.bias"] = G.colsum(dx)
+        G.linear_wgrad(dxb, a, sink.get(f"{b}.self_attn.out_proj.weight"))
+        G.colsum(dx, sink.get(f"{b}.self_attn.out_proj.bias"))
         da = G.linear_dgrad(dxb, w[f"{i}.o_t"], zb)
         dqkv = G.attention_bwd(qkv, da, n_seq, T, self.heads, causal, km)
         h1 = ops.layernorm(x, self._p(f"{b}.layer_norm1.weight"), self._p(f"{b}.layer_norm1.bias"), self.eps)
-        dwqkv = G.linear_wgrad(dqkv, h1)
-        dbqkv = G.colsum(dqkv)
-        for j, n in enumerate("qkv"):
-            grads[f"{b}.self_attn.{n}_proj.weight"] = dwqkv[j * d:(j + 1) * d]
-            grads[f"{b}.self_attn.{n}_proj.bias"] = dbqkv[j * d:(j + 1) * d]
+        wq, bq = sink.qkv(b, d)
+        G.linear_wgrad(dqkv, h1, wq)
+        G.colsum(dqkv, bq)
         dh1 = G.linear_dgrad(dqkv, w[f"{i}.qkv_t"], zb)
-        dw, db = ln_grads("layer_norm1")
-        G.layernorm_bwd(x, self._p(f"{b}.layer_norm1.weight"), self.eps, dh1, dw, db, dx=dx, accumulate=True)
+        G.layernorm_bwd(x, self._p(f"{b}.layer_norm1.weight"), self.eps, dh1, sink.get(f"{b}.layer_norm1.weight"),
+                        sink.get(f"{b}.layer_norm1.bias"), dx=dx, accumulate=True)
 
     # -- whole towers -------------------------------------------------------------------------
     def forward_images(self, patches: torch.Tensor, n: int):
@@ -207,70 +202,169 @@ class TrainTower:
                                                  out.data_ptr(), ops._stream()))
         return out
 
-    def backward(self, saved, dfeat: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """Gradients of every parameter of the tower given d(loss)/d(features) [n, proj]."""
-        grads: Dict[str, torch.Tensor] = {}
+    def backward(self, saved, dfeat: torch.Tensor, sink: "GradSink"):
+        """Adds the gradient of every parameter of the tower, given d(loss)/d(features) [n, proj], to `sink`."""
         d, n, T = self.d, saved["n"], saved["T"]
         dev = self.device
         proj_name = "visual_projection.weight" if self.vision else "text_projection.weight"
         ln_name = "vision_model.post_layernorm" if self.vision else "text_model.final_layer_norm"
         dfeat = dfeat.to(F32).contiguous()
-        grads[proj_name] = G.matmul_f32(dfeat, saved["pl"], transA=True)
+        G.matmul_f32(dfeat, saved["pl"], transA=True, out=sink.get(proj_name), accumulate=True)
         dpl = G.matmul_f32(dfeat, self._p(proj_name))
-        dw, db = torch.zeros(d, dtype=F32, device=dev), torch.zeros(d, dtype=F32, device=dev)
-        grads[f"{ln_name}.weight"], grads[f"{ln_name}.bias"] = dw, db
-        dxp = G.layernorm_bwd(saved["xp"], self._p(f"{ln_name}.weight"), self.eps, dpl, dw, db)
+        dxp = G.layernorm_bwd(saved["xp"], self._p(f"{ln_name}.weight"), self.eps, dpl, sink.get(f"{ln_name}.weight"),
+                              sink.get(f"{ln_name}.bias"))
         dx = torch.zeros((n * T, d), dtype=F32, device=dev)
         G.rows_scatter_add(dxp, saved["rows"], dx)
         for i in reversed(range(self.L)):
-            self._layer_backward(i, saved["layers"][i], dx, n, T, not self.vision, saved["km"], grads)
+            self._layer_backward(i, saved["layers"][i], dx, n, T, not self.vision, saved["km"], sink)
             saved["layers"][i] = None
         if self.vision:
-            dw, db = torch.zeros(d, dtype=F32, device=dev), torch.zeros(d, dtype=F32, device=dev)
-            grads["vision_model.pre_layrnorm.weight"], grads["vision_model.pre_layrnorm.bias"] = dw, db
-            demb = G.layernorm_bwd(saved["emb"], self._p("vision_model.pre_layrnorm.weight"), self.eps, dx, dw, db)
-            dpos = G.colsum(demb.view(n, T * d)).view(T, d)
-            grads["vision_model.embeddings.position_embedding.weight"] = dpos
-            grads["vision_model.embeddings.class_embedding"] = dpos[0]
+            demb = G.layernorm_bwd(saved["emb"], self._p("vision_model.pre_layrnorm.weight"), self.eps, dx,
+                                   sink.get("vision_model.pre_layrnorm.weight"), sink.get("vision_model.pre_layrnorm.bias"))
+            flat = demb.view(n, T * d)
+            G.colsum(flat, sink.get("vision_model.embeddings.position_embedding.weight").view(-1))
+            G.colsum(flat[:, :d], sink.get("vision_model.embeddings.class_embedding"))   # row 0 of every image
             dpatch = G.cast_bf16(demb.view(n, T, d)[:, 1:, :].contiguous().view(n * (T - 1), d))
-            dwp = G.linear_wgrad(dpatch, saved["patches"])
-            pshape = self.params["vision_model.embeddings.patch_embedding.weight"].shape
-            grads["vision_model.embeddings.patch_embedding.weight"] = dwp[:, : 3 * self.cfg.patch ** 2].reshape(pshape)
+            gp = sink.get("vision_model.embeddings.patch_embedding.weight")
+            k_real = 3 * self.cfg.patch ** 2
+            if saved["patches"].shape[1] == k_real:
+                G.linear_wgrad(dpatch, saved["patches"], gp.view(d, k_real))
+            else:                                   # padded patch rows (ViT-L/14: 588 -> 640)
+                gp.view(d, k_real).add_(G.linear_wgrad(dpatch, saved["patches"])[:, :k_real])
         else:
-            tok = self.params["text_model.embeddings.token_embedding.weight"]
-            dtok = torch.zeros(tok.shape, dtype=F32, device=dev)
-            G.rows_scatter_add(dx, saved["ids"].reshape(-1), dtok)
-            grads["text_model.embeddings.token_embedding.weight"] = dtok
-            posw = self.params["text_model.embeddings.position_embedding.weight"]
-            dpos = torch.zeros(posw.shape, dtype=F32, device=dev)
-            dpos[:T] = G.colsum(dx.view(n, T * d)).view(T, d)
-            grads["text_model.embeddings.position_embedding.weight"] = dpos
-        return grads
+            G.rows_scatter_add(dx, saved["ids"].reshape(-1), sink.get("text_model.embeddings.token_embedding.weight"))
+            gpos = sink.get("text_model.embeddings.position_embedding.weight")
+            G.colsum(dx.view(n, T * d), gpos[:T].view(-1))
+
+
+class GradSink:
+    """Where a tower's backward adds its parameter gradients: the persistent views of a `FlatParameters`
+    gradient buffer, or zero-initialised tensors created on demand and handed back to autograd."""
+
+    def __init__(self, tower: TrainTower):
+        self.tower = tower
+        self.flat = tower.flat
+        self.loose: Dict[str, torch.Tensor] = {}
+
+    def get(self, name: str) -> torch.Tensor:
+        if self.flat is not None:
+            return self.flat.grad_view(self.tower.flat_prefix + name)
+        if name not in self.loose:
+            p = self.tower.params[name]
+            self.loose[name] = torch.zeros(p.shape, dtype=F32, device=p.device)
+        return self.loose[name]
+
+    def qkv(self, layer: str, d: int):
+        """[3d, d] and [3d] gradients of the fused q, k, v projection of `layer`."""
+        wn = [f"{layer}.self_attn.{n}_proj.weight" for n in "qkv"]
+        bn = [f"{layer}.self_attn.{n}_proj.bias" for n in "qkv"]
+        if self.flat is not None:
+            pre = self.tower.flat_prefix
+            return (self.flat.grad_span([pre + n for n in wn]).view(3 * d, d), self.flat.grad_span([pre + n for n in bn]))
+        if wn[0] not in self.loose:
+            dev = self.tower.device
+            w, b = torch.zeros((3 * d, d), dtype=F32, device=dev), torch.zeros(3 * d, dtype=F32, device=dev)
+            for j in range(3):
+                self.loose[wn[j]], self.loose[bn[j]] = w[j * d:(j + 1) * d], b[j * d:(j + 1) * d]
+            self.loose[layer + ".qkv_w"], self.loose[layer + ".qkv_b"] = w, b
+        return self.loose[layer + ".qkv_w"], self.loose[layer + ".qkv_b"]
+
+    def autograd_outputs(self):
+        """One entry per tower parameter for autograd: None where the gradient already went into the flat buffer."""
+        out = []
+        for name, p in zip(self.tower.names, self.tower.param_list()):
+            g = None if self.flat is not None else self.loose.get(name)
+            out.append(g.reshape(p.shape) if (g is not None and p.requires_grad) else None)
+        return out
+
+
+class FlatParameters:
+    """All parameters of a module in ONE fp32 buffer and their gradients in a second one.
+
+    Each parameter's `.data` / `.grad` become views of the two buffers (state_dict / load_state_dict keep
+    working).  The towers' backward adds weight gradients straight into the gradient buffer (split-K atomics of
+    the weight-gradient GEMM land there), the optimizer is one kernel launch over the whole buffer, and the
+    gradient all-reduce is one collective per bucket of the same buffer with no packing copies."""
+
+    ALIGN = 4   # elements (16 bytes); q / k / v tensors are multiples of it, so fused views stay gap-free
+
+    def __init__(self, named_params):
+        named_params = [(n, p) for n, p in named_params]
+        off, self.index = 0, {}
+        for n, p in named_params:
+            self.index[n] = (off, p.numel(), tuple(p.shape))
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        dev = named_params[0][1].device
+        self.total = off
+        self.data = torch.zeros(off, dtype=F32, device=dev)
+        self.grad = torch.zeros(off, dtype=F32, device=dev)
+        self.params = [p for _, p in named_params]
+        with torch.no_grad():
+            for n, p in named_params:
+                o, cnt, shape = self.index[n]
+                self.data[o:o + cnt].copy_(p.detach().reshape(-1))
+                p.data = self.data[o:o + cnt].view(shape)
+                p.grad = self.grad[o:o + cnt].view(shape)
+
+    def grad_view(self, name: str) -> torch.Tensor:
+        o, cnt, shape = self.index[name]
+        return self.grad[o:o + cnt].view(shape)
+
+    def grad_span(self, names) -> torch.Tensor:
+        """1-D view over the gradients of parameters that lie back to back."""
+        o0 = self.index[names[0]][0]
+        o = o0
+        for n in names:
+            assert self.index[n][0] == o, f"{n} is not adjacent to its predecessor in the flat buffer"
+            o += self.index[n][1]
+        return self.grad[o0:o]
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for n, p in zip(self.index, self.params):    # re-attach views a foreign zero_grad(set_to_none=True) dropped
+            if p.grad is None:
+                p.grad = self.grad_view(n)
+
+    def mark_updated(self):
+        for p in self.params:
+            torch.autograd.graph.increment_version(p)
 
 
 class _TowerFn(torch.autograd.Function):
-    """features = tower(inputs); the tower's parameters are inputs of the node so that autograd
-    delivers their gradients."""
+    """features = tower(inputs).  The tower's parameters are inputs of the node so that autograd knows the output
+    depends on them; their gradients are returned to autograd, or added to the flat gradient buffer directly."""
 
     @staticmethod
-    def forward(ctx, tower: TrainTower, run, *params):
-        feats, saved = run()
-        ctx.tower, ctx.saved = tower, saved
-        return feats
+    def forward(ctx, tower: TrainTower, run, chunks, *params):
+        """run(lo, hi) -> (features, saved) for items lo..hi; chunks: list of (lo, hi).  With more than one chunk
+        nothing is saved and backward recomputes each chunk's forward (the reference wraps its feature calls in
+        torch.utils.checkpoint the same way, llava_clip_model_v3.py:52-83)."""
+        ctx.tower, ctx.run, ctx.chunks = tower, run, chunks
+        if len(chunks) == 1:
+            feats, ctx.saved = run(*chunks[0])
+            return feats
+        ctx.saved = None
+        return torch.cat([run(lo, hi)[0] for lo, hi in chunks], dim=0)
 
     @staticmethod
     def backward(ctx, dfeat):
-        grads = ctx.tower.backward(ctx.saved, dfeat)
-        ctx.saved = None
-        out = []
-        for name, p in zip(ctx.tower.names, ctx.tower.param_list()):
-            g = grads.get(name)
-            out.append(g.reshape(p.shape) if (g is not None and p.requires_grad) else None)
-        return (None, None) + tuple(out)
+        sink = GradSink(ctx.tower)
+        if ctx.saved is not None:
+            ctx.tower.backward(ctx.saved, dfeat, sink)
+            ctx.saved = None
+        else:
+            for lo, hi in ctx.chunks:
+                _, saved = ctx.run(lo, hi)
+                ctx.tower.backward(saved, dfeat[lo:hi], sink)
+        return (None, None, None) + tuple(sink.autograd_outputs())
 
 
 def encode_images(tower: TrainTower, patches: torch.Tensor, n: int) -> torch.Tensor:
-    return _TowerFn.apply(tower, lambda: tower.forward_images(patches, n), *tower.param_list())
+    P = tower.cfg.n_patches
+    c = tower.recompute_chunk
+    chunks = [(0, n)] if not c or n <= c else [(lo, min(n, lo + c)) for lo in range(0, n, c)]
+    return _TowerFn.apply(tower, lambda lo, hi: tower.forward_images(patches[lo * P: hi * P], hi - lo), chunks,
+                          *tower.param_list())
 
 
 def encode_text(tower: TrainTower, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
@@ -290,7 +384,7 @@ def encode_text(tower: TrainTower, input_ids: torch.Tensor, attention_mask: Opti
     if attention_mask is not None:
         am = attention_mask[:, :T].to(dev, torch.int32).contiguous()
     rows = torch.from_numpy((np.arange(len(pos)) * T + pos).astype(np.int32)).to(dev)
-    return _TowerFn.apply(tower, lambda: tower.forward_text(ids, am, rows), *tower.param_list())
+    return _TowerFn.apply(tower, lambda lo, hi: tower.forward_text(ids, am, rows), [(0, ids.shape[0])], *tower.param_list())
 
 
 class _SimilarityFn(torch.autograd.Function):
@@ -315,7 +409,7 @@ class _SimilarityFn(torch.autograd.Function):
         dth = G.matmul_f32(dl, ih, alpha=s)                  # [K, E]
         dih = G.matmul_f32(dl, th, transA=True, alpha=s)     # [N, E]
         # d/d(logit_scale) of s <th_k, ih_n> is the logit itself: sum_kn dl logit = sum_k <dth_k, th_k>
-        dls = G.matmul_f32(dth.view(1, -1), th.view(1, -1), transB=True).view(())
+        dls = G.dot_f32(dth, th)
         return G.normalize_bwd(text, dth), G.normalize_bwd(img, dih), dls, None
 
 
@@ -350,17 +444,25 @@ def segment_mean(probs: torch.Tensor, seg: torch.Tensor, n_groups: int, seg_host
 # ---------------------------------------------------------------------------------------------
 class Adam:
     """torch.optim.Adam's update (scripts/train_sgclip.py:232-241 uses its defaults: betas (0.9, 0.999),
-    eps 1e-8, no weight decay) as one HIP kernel launch per parameter."""
+    eps 1e-8, no weight decay) as HIP kernel launches: one per parameter, or ONE over the whole buffer when
+    given a `FlatParameters`."""
 
-    def __init__(self, params: Sequence[nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        self.flat = params if isinstance(params, FlatParameters) else None
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
-        self.m = [torch.zeros_like(p, dtype=F32) for p in self.params]
-        self.v = [torch.zeros_like(p, dtype=F32) for p in self.params]
+        if self.flat is not None:
+            self.params = list(self.flat.params)
+            self.m, self.v = torch.zeros_like(self.flat.data), torch.zeros_like(self.flat.data)
+        else:
+            self.params = [p for p in params if p.requires_grad]
+            self.m = [torch.zeros_like(p, dtype=F32) for p in self.params]
+            self.v = [torch.zeros_like(p, dtype=F32) for p in self.params]
 
     def zero_grad(self, set_to_none: bool = True):
+        if self.flat is not None:
+            self.flat.zero_grad()
+            return
         for p in self.params:
             if set_to_none:
                 p.grad = None
@@ -370,15 +472,21 @@ class Adam:
     @torch.no_grad()
     def step(self):
         self.step_count += 1
+        b1, b2 = self.betas
+        if self.flat is not None:
+            G.adamw(self.flat.data, self.flat.grad, self.m, self.v, self.step_count, self.lr, b1, b2, self.eps,
+                    self.weight_decay)
+            self.flat.mark_updated()
+            return
         for p, m, v in zip(self.params, self.m, self.v):
             if p.grad is None:
                 continue
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            G.adamw(p.data, g, m, v, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay)
+            G.adamw(p.data, g, m, v, self.step_count, self.lr, b1, b2, self.eps, self.weight_decay)
             torch.autograd.graph.increment_version(p)   # the towers rebuild their bf16 copies when this changes
 
 
-def allreduce_gradients(params: Sequence[nn.Parameter], group=None, bucket_bytes: int = 256 << 20):
+def allreduce_gradients(params, group=None, bucket_bytes: int = 256 << 20):
     """Average `.grad` over the ranks of `group` (RCCL on GPUs): gradients are packed into flat fp32
     buckets of about `bucket_bytes` so that each all-reduce is large enough to run at link bandwidth.
     Parameters without a gradient on this rank contribute zeros (every rank walks the same list)."""
@@ -386,6 +494,16 @@ def allreduce_gradients(params: Sequence[nn.Parameter], group=None, bucket_bytes
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     world = dist.get_world_size(group)
+    if isinstance(params, FlatParameters):
+        # the gradients already lie in one buffer: all-reduce it in place, bucket by bucket
+        flat, step = params.grad, max(1, bucket_bytes // 4)
+        avg = dist.get_backend(group) == "nccl"
+        for lo in range(0, flat.numel(), step):
+            piece = flat[lo: lo + step]
+            dist.all_reduce(piece, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group)
+            if not avg:
+                piece.div_(world)
+        return
     bucket, size = [], 0
 
     def flush():

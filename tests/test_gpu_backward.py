@@ -61,6 +61,37 @@ def test_quick_gelu_and_its_gradient(dev):
     assert (du.float() - uf.grad).abs().max().item() <= 3e-2
 
 
+def test_quick_gelu_tail(dev):
+    u = _randn((1003,), dev, 3, 2.0, torch.bfloat16)
+    dg = _randn((1003,), dev, 4, 1.0, torch.bfloat16)
+    uf = u.float()
+    sg = torch.sigmoid(1.702 * uf)
+    torch.cuda.synchronize()
+    assert (G.quick_gelu(u).float() - uf * sg).abs().max().item() <= 2e-2
+    assert (G.quick_gelu_bwd(u, dg).float() - dg.float() * (sg + 1.702 * uf * sg * (1 - sg))).abs().max().item() <= 3e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 768, 6400), (3072, 768, 44800), (100, 130, 640), (512, 2048, 960), (200, 256, 64)])
+def test_gemm_split_k_accumulates_atomically(dev, M, N, K):
+    A = _randn((M, K), dev, 50, 1.0, torch.bfloat16)
+    W = _randn((N, K), dev, 51, 1.0, torch.bfloat16)
+    base = _randn((M, N), dev, 52)
+    out = base.clone()
+    ops.gemm_bf16(A, W, out, _lib.EPI_F32_ATOMIC)
+    ref = base.double() + A.double() @ W.double().t()
+    torch.cuda.synchronize()
+    assert (out.double() - ref).abs().max().item() <= 2e-3 * K ** 0.5
+
+
+@pytest.mark.parametrize("M,out_f,in_f", [(6400, 768, 768), (850, 3072, 768), (100, 64, 128)])
+def test_linear_wgrad(dev, M, out_f, in_f):
+    dy = _randn((M, out_f), dev, 53, 1.0, torch.bfloat16)
+    x = _randn((M, in_f), dev, 54, 1.0, torch.bfloat16)
+    dw = G.linear_wgrad(dy, x)
+    torch.cuda.synchronize()
+    assert _rel(dw, dy.float().t() @ x.float()) <= 1e-3
+
+
 def test_cast(dev):
     x = _randn((1000,), dev, 5, 10.0)
     assert torch.equal(G.cast_bf16(x), x.to(torch.bfloat16))

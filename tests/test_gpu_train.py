@@ -128,3 +128,64 @@ def test_a_few_adam_steps_raise_the_target_probabilities():
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0] * 0.8, losses
+
+
+def _grads_of(model):
+    return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def test_flat_parameters_and_chunked_recompute_give_the_same_gradients():
+    """The same batch through (a) loose parameters, (b) flat buffers with in-place gradient accumulation,
+    (c) flat buffers + image towers recomputed 5 crops at a time: same loss, same gradients (up to the order
+    of the fp32 atomic additions); two backward passes accumulate; state_dict survives flattening."""
+    b = make_clip_batch(12, n_videos=1, frames=3, objects=3, H=96, W=128, k_cate=4, k_unary=5, k_binary=3, min_box=12,
+                        max_box=90)
+    kw = b.forward_kwargs()
+    results = []
+    for mode in ("loose", "flat", "flat+recompute"):
+        cfg, sd, tok, model = _setup(24, float(np.log(10.0)))
+        model.enable_training()
+        if mode != "loose":
+            flat = model.flatten_parameters()
+            assert all(torch.equal(v.cpu(), sd[k]) for k, v in model.state_dict().items())
+        if mode == "flat+recompute":
+            model.set_recompute_chunk(5)
+        loss, _ = _loss(model(**kw), 3)
+        loss.backward()
+        torch.cuda.synchronize()
+        results.append((loss.item(), _grads_of(model)))
+        if mode == "flat":
+            once = flat.grad.clone()
+            loss2, _ = _loss(model(**kw), 3)
+            loss2.backward()
+            assert ((flat.grad - 2 * once).norm() / (2 * once).norm()).item() <= 1e-4     # accumulation
+            flat.zero_grad()
+            assert float(flat.grad.abs().max()) == 0.0
+    (l0, g0), (l1, g1), (l2, g2) = results
+    assert abs(l0 - l1) <= 1e-5 * max(1, abs(l0)) and abs(l0 - l2) <= 1e-5 * max(1, abs(l0))
+    for other in (g1, g2):
+        assert set(other) == set(g0)
+        a = torch.cat([g0[k].reshape(-1) for k in sorted(g0)])
+        o = torch.cat([other[k].reshape(-1) for k in sorted(g0)])
+        assert ((a - o).norm() / a.norm()).item() <= 1e-4
+
+
+def test_flat_adam_matches_per_parameter_adam():
+    b = make_clip_batch(13, n_videos=1, frames=2, objects=3, H=96, W=128, k_cate=4, k_unary=5, k_binary=3, min_box=12,
+                        max_box=90)
+    kw = b.forward_kwargs()
+    after = []
+    for use_flat in (False, True):
+        cfg, sd, tok, model = _setup(25, float(np.log(10.0)))
+        model.enable_training()
+        opt = training.Adam(model.flatten_parameters() if use_flat else model.parameters(), lr=1e-3)
+        for _ in range(2):
+            opt.zero_grad()
+            loss, _ = _loss(model(**kw), 4)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        after.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+    a = torch.cat([after[0][k].reshape(-1) for k in sorted(after[0])])
+    o = torch.cat([after[1][k].reshape(-1) for k in sorted(after[0])])
+    assert (a - o).abs().max().item() <= 2e-4
