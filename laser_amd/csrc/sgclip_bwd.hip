@@ -4,6 +4,8 @@
 // does the heavy data- and weight-gradient products (sgclip_gemm_bf16 on transposed operands).
 #include "common.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 namespace sgclip {
@@ -309,6 +311,218 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const bf16_t *__rest
 }
 
 // ---------------------------------------------------------------------------
+// The same adjoint on the matrix cores (v_mfma_f32_16x16x32_bf16), T padded to TP = 32 / 64 / 96 / 128.
+// One workgroup (4 waves) per (sequence, head).
+//   load:    Q, K, V, dO row-major [TP][72] (stride 72 keeps 16-byte fragment reads conflict free) and
+//            Q^T, K^T, dO^T [64][TP + 8], zero padded
+//   phase A: wave w owns query tiles w, w + 4: S = Q K^T and dP = dO V^T for whole rows, row softmax and
+//            D = sum_k P dP by in-register + 16-lane reductions, dS = P (dP - D) / 8; P and dS kept as packed bf16
+//   write:   P^T, dS, dS^T [TP][TP + 8] over the (now dead) row-major operands
+//   phase B: dV = P^T dO, dK = dS^T Q, dQ = dS K, each wave two 16-row tiles x 64 columns
+// ---------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int TP>
+__global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+                                                                 bf16_t *__restrict__ dqkv, int T, int heads, int causal,
+                                                                 const int32_t *__restrict__ key_mask) {
+    constexpr int LDR = 72, LDT = TP + 8, NT = TP / 16, RT = (NT + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t *Qt = (bf16_t *)smem, *Kt = Qt + 64 * LDT, *dOt = Kt + 64 * LDT;
+    bf16_t *rm = dOt + 64 * LDT;
+    bf16_t *Qr = rm, *Kr = Qr + TP * LDR, *Vr = Kr + TP * LDR, *dOr = Vr + TP * LDR;
+    bf16_t *Pt = rm, *dS = Pt + TP * LDT, *dSt = dS + TP * LDT;   // phase B, over the row-major operands
+
+    const int d = heads * 64;
+    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
+    const size_t ld = (size_t)3 * d;
+    const bf16_t *base = qkv + (size_t)seq * T * ld + head * 64;
+    const bf16_t *dobase = dout + (size_t)seq * T * d + head * 64;
+    const int32_t *km = key_mask ? key_mask + (size_t)seq * T : nullptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // ---- load: consecutive lanes take consecutive rows, so the transposed 2-byte stores are conflict free
+    for (int idx = threadIdx.x; idx < TP * 8; idx += 256) {
+        const int t = idx % TP, ch = idx / TP;
+        bf16x8 q = {}, k = {}, v = {}, o = {};
+        if (t < T) {
+            const bf16_t *r = base + (size_t)t * ld + ch * 8;
+            q = *(const bf16x8 *)r;
+            k = *(const bf16x8 *)(r + d);
+            v = *(const bf16x8 *)(r + 2 * d);
+            o = *(const bf16x8 *)(dobase + (size_t)t * d + ch * 8);
+        }
+        *(bf16x8 *)(Qr + t * LDR + ch * 8) = q;
+        *(bf16x8 *)(Kr + t * LDR + ch * 8) = k;
+        *(bf16x8 *)(Vr + t * LDR + ch * 8) = v;
+        *(bf16x8 *)(dOr + t * LDR + ch * 8) = o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            Qt[(ch * 8 + j) * LDT + t] = q[j];
+            Kt[(ch * 8 + j) * LDT + t] = k[j];
+            dOt[(ch * 8 + j) * LDT + t] = o[j];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase A
+    bf16x4 pP[RT][NT], pS[RT][NT];
+#pragma unroll
+    for (int r2 = 0; r2 < RT; r2++) {
+        const int rt = wave + 4 * r2;
+        if (rt >= NT) break;
+        f32x4_t S[NT], dP[NT];
+        bf16x8 aq[2], ao[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            aq[kk] = *(const bf16x8 *)(Qr + (rt * 16 + frow) * LDR + kk * 32 + fq * 8);
+            ao[kk] = *(const bf16x8 *)(dOr + (rt * 16 + frow) * LDR + kk * 32 + fq * 8);
+        }
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++) {
+            S[ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            dP[ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                const bf16x8 bk = *(const bf16x8 *)(Kr + (ct * 16 + frow) * LDR + kk * 32 + fq * 8);
+                const bf16x8 bv = *(const bf16x8 *)(Vr + (ct * 16 + frow) * LDR + kk * 32 + fq * 8);
+                S[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[kk], bk, S[ct], 0, 0, 0);
+                dP[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[kk], bv, dP[ct], 0, 0, 0);
+            }
+        }
+        // element e of tile ct: query i = rt*16 + fq*4 + e, key k = ct*16 + frow
+        float mx[4] = {-1.0e30f, -1.0e30f, -1.0e30f, -1.0e30f};
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++) {
+            const int k = ct * 16 + frow;
+            const bool kok = k < T && (!km || km[k < T ? k : 0] != 0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = rt * 16 + fq * 4 + e;
+                const bool ok = kok && (!causal || k <= i);
+                S[ct][e] = ok ? S[ct][e] * 0.125f : -1.0e30f;
+                mx[e] = fmaxf(mx[e], S[ct][e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) mx[e] = fmaxf(mx[e], __shfl_xor(mx[e], o));
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float p = S[ct][e] > -0.5e30f ? __expf(S[ct][e] - mx[e]) : 0.f;
+                S[ct][e] = p;
+                sum[e] += p;
+            }
+        float dsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum[e] += __shfl_xor(sum[e], o);
+            sum[e] = sum[e] > 0.f ? 1.0f / sum[e] : 0.f;
+        }
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                S[ct][e] *= sum[e];
+                dsum[e] += S[ct][e] * dP[ct][e];
+            }
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) dsum[e] += __shfl_xor(dsum[e], o);
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                pP[r2][ct][e] = (bf16_t)S[ct][e];
+                pS[r2][ct][e] = (bf16_t)(S[ct][e] * (dP[ct][e] - dsum[e]) * 0.125f);
+            }
+    }
+    __syncthreads();   // every wave has finished reading the row-major operands
+
+    // ---- write P^T, dS^T (4 consecutive queries per store) and dS
+#pragma unroll
+    for (int r2 = 0; r2 < RT; r2++) {
+        const int rt = wave + 4 * r2;
+        if (rt >= NT) break;
+#pragma unroll
+        for (int ct = 0; ct < NT; ct++) {
+            const int k = ct * 16 + frow, i0 = rt * 16 + fq * 4;
+            *(bf16x4 *)(Pt + k * LDT + i0) = pP[r2][ct];
+            *(bf16x4 *)(dSt + k * LDT + i0) = pS[r2][ct];
+#pragma unroll
+            for (int e = 0; e < 4; e++) dS[(i0 + e) * LDT + k] = pS[r2][ct][e];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B
+    bf16_t *obase = dqkv + (size_t)seq * T * ld + head * 64;
+#pragma unroll
+    for (int r2 = 0; r2 < RT; r2++) {
+        const int rt = wave + 4 * r2;
+        if (rt >= NT) break;
+        f32x4_t aV[4], aK[4], aQ[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            aV[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            aK[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            aQ[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s0 = 0; s0 < TP; s0 += 32) {
+            const bf16x8 fp = *(const bf16x8 *)(Pt + (rt * 16 + frow) * LDT + s0 + fq * 8);
+            const bf16x8 fst = *(const bf16x8 *)(dSt + (rt * 16 + frow) * LDT + s0 + fq * 8);
+            const bf16x8 fs = *(const bf16x8 *)(dS + (rt * 16 + frow) * LDT + s0 + fq * 8);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const bf16x8 bo = *(const bf16x8 *)(dOt + (c * 16 + frow) * LDT + s0 + fq * 8);
+                const bf16x8 bq = *(const bf16x8 *)(Qt + (c * 16 + frow) * LDT + s0 + fq * 8);
+                const bf16x8 bk = *(const bf16x8 *)(Kt + (c * 16 + frow) * LDT + s0 + fq * 8);
+                aV[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp, bo, aV[c], 0, 0, 0);
+                aK[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fst, bq, aK[c], 0, 0, 0);
+                aQ[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fs, bk, aQ[c], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int t = rt * 16 + fq * 4 + e;
+            if (t >= T) continue;
+            bf16_t *o = obase + (size_t)t * ld + frow;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                o[c * 16] = (bf16_t)aQ[c][e];
+                o[d + c * 16] = (bf16_t)aK[c][e];
+                o[2 * d + c * 16] = (bf16_t)aV[c][e];
+            }
+        }
+    }
+}
+
+template <int TP>
+static void attention_bwd_mfma_launch(const bf16_t *qkv, const bf16_t *dout, bf16_t *dqkv, int n_seq, int T, int heads,
+                                      int causal, const int32_t *km, hipStream_t stream) {
+    constexpr int LDT = TP + 8;
+    constexpr size_t phase_a = (size_t)4 * TP * 72 * 2, phase_b = (size_t)3 * TP * LDT * 2;
+    constexpr size_t lds = (size_t)3 * 64 * LDT * 2 + (phase_a > phase_b ? phase_a : phase_b);
+    static_assert(lds <= 160 * 1024, "attention backward tile exceeds the LDS");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)attention_bwd_mfma_kernel<TP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(attention_bwd_mfma_kernel<TP>, dim3((unsigned)(n_seq * heads)), dim3(256), lds, stream, qkv, dout, dqkv,
+                       T, heads, causal, km);
+}
+
+// ---------------------------------------------------------------------------
 // C[M][N] (+)= alpha * op(A) op(B), fp32, 64 x 64 tiles (the small products of the fp32 tail:
 // projection, similarity).  op(A) is [M][K]: A[m][k] or, transposed, A[k][m]; likewise op(B) [K][N].
 // ---------------------------------------------------------------------------
@@ -554,6 +768,25 @@ extern "C" int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, v
     if (T > 128) {
         set_error("sgclip_attention_bwd: T=%d > 128 is not supported by the short-sequence backward kernel", T);
         return SGCLIP_EINVAL;
+    }
+    static int use_valu = -1;   // SGCLIP_ATTN_BWD_VALU=1: the plain VALU kernel (cross-check)
+    if (use_valu < 0) {
+        const char *e = getenv("SGCLIP_ATTN_BWD_VALU");
+        use_valu = e ? atoi(e) : 0;
+    }
+    if (!use_valu && !((uintptr_t)qkv_dev & 15) && !((uintptr_t)dout_dev & 15)) {
+        const bf16_t *q = (const bf16_t *)qkv_dev, *o = (const bf16_t *)dout_dev;
+        bf16_t *g = (bf16_t *)dqkv_dev;
+        hipStream_t hs = (hipStream_t)stream;
+        if (T <= 32)
+            attention_bwd_mfma_launch<32>(q, o, g, n_seq, T, heads, causal, key_mask_dev, hs);
+        else if (T <= 64)
+            attention_bwd_mfma_launch<64>(q, o, g, n_seq, T, heads, causal, key_mask_dev, hs);
+        else if (T <= 96)
+            attention_bwd_mfma_launch<96>(q, o, g, n_seq, T, heads, causal, key_mask_dev, hs);
+        else
+            attention_bwd_mfma_launch<128>(q, o, g, n_seq, T, heads, causal, key_mask_dev, hs);
+        return launch_check("sgclip_attention_bwd");
     }
     const size_t lds = (size_t)4 * T * 64 * sizeof(bf16_t) + (size_t)T * T * sizeof(float);
     static bool attr = false;
