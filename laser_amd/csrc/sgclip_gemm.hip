@@ -562,11 +562,170 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
     }
 }
 
+#define SG_MFMA 0x008
+#define SG_VMEM_RD 0x020
+#define SG_DS_RD 0x100
+
+// ---------------------------------------------------------------------------
+// 256 x 256 tile, 64-deep stages: every DMA piece is 8 rows x 128 contiguous bytes, a whole
+// cache line per row.  The L2 serves a CU a fixed number of requests per unit time whether a
+// request is 64 or 128 bytes (measured: 64 GB/s per CU in 64-byte row pieces, 128 GB/s in
+// 128-byte ones), so the 32-deep stages above fetch operands at half the rate.
+// Two 64 KiB slots; a stage is two 32-deep MFMA sub-steps with register double-buffered
+// fragments, and ONE barrier per stage: at the start of sub-step 1 of stage s every wave has
+// read all of stage s (its slot takes the DMA of stage s+2) and stage s+1 has landed.
+// Needs K % 64 == 0 and K >= 128.
+// ---------------------------------------------------------------------------
+constexpr int P64_OP = 256 * 128, P64_SLOT = 2 * P64_OP;  // 64 KiB
+
+template <bool SYNC, bool DMA, bool READ, int DBG>
+__device__ __forceinline__ void pipe64_substep(f32x4 (&acc)[4][8], const bf16x8 (&ca)[4], const bf16x8 (&cb)[8],
+                                               bf16x8 (&na)[4], bf16x8 (&nb)[8], const unsigned char *rd_a,
+                                               const unsigned char *rd_b, unsigned char *wr_slot,
+                                               const bf16_t *const (&gsrc)[8], int wave) {
+    if (SYNC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (DMA && DBG != 3) {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc[q]), LDS_PTR(wr_slot + (wave + 8 * q) * 1024), 16, 0, 0);
+    }
+    if (READ) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) na[i] = *(const bf16x8 *)(rd_a + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 8; j++) nb[j] = *(const bf16x8 *)(rd_b + j * 2048);
+    }
+    if (DBG == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) asm volatile("" ::"v"(ca[i]));
+#pragma unroll
+        for (int j = 0; j < 8; j++) asm volatile("" ::"v"(cb[j]));
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+    if (DMA && DBG != 3) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 1, 0);
+        }
+    }
+    if (READ) {
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            // one fragment read per two MFMAs: at one per MFMA the two waves of a SIMD together ask the LDS for
+            // 1 KiB per 16-cycle MFMA slot on every SIMD, which is the LDS's whole bandwidth (measured: 24 % slower)
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DS_RD, 1, 0);
+        }
+    }
+}
+
+template <int EPI, int DBG>
+__global__ __launch_bounds__(512, 2) void gemm_pipe64_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    split_k_setup(g);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 rows x 128 columns
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = swz / g.tiles_n, tn = swz - tm * g.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[2][4], fb[2][8];
+
+    // this wave's eight pieces of a stage: pieces wave + 8 q, q < 4 of A (rows 8 piece ..), q >= 4 of W
+    const bf16_t *gsrc[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int piece = wave + 8 * (q & 3);
+        const int row = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const bool isw = q >= 4;
+        int grow = (isw ? n0 : m0) + row;
+        const int lim = isw ? g.N : g.M;
+        grow = grow < lim ? grow : lim - 1;
+        gsrc[q] = (isw ? g.W + (size_t)grow * g.ldw : g.A + (size_t)grow * g.lda) + c * 8;
+    }
+    // LDS piece order inside a slot: A pieces 0..31, then W pieces 0..31 -> piece (wave + 8 q) for q < 4, +32 for q >= 4
+    // (wr_slot + (wave + 8 q) * 1024 with q = 4..7 lands in the W half because 8 * 4 = 32 pieces = P64_OP bytes)
+    const int a0 = lds_off(wm * 64 + frow, fq), b0 = P64_OP + lds_off(wn * 128 + frow, fq);
+    const int a1 = lds_off(wm * 64 + frow, 4 + fq), b1 = P64_OP + lds_off(wn * 128 + frow, 4 + fq);
+
+    const int ns = g.K / 64;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc[q] + t * 64), LDS_PTR(lds + t * P64_SLOT + (wave + 8 * q) * 1024),
+                                             16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; q++) gsrc[q] += 128;  // next stage to fetch: 2
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; i++) fa[0][i] = *(const bf16x8 *)(lds + a0 + i * 2048);
+#pragma unroll
+    for (int j = 0; j < 8; j++) fb[0][j] = *(const bf16x8 *)(lds + b0 + j * 2048);
+
+    int s = 0;
+    for (; s < ns - 2; s++) {
+        unsigned char *cur = lds + (s & 1) * P64_SLOT, *nxt = lds + ((s + 1) & 1) * P64_SLOT;
+        pipe64_substep<false, false, true, DBG>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, gsrc, wave);
+        pipe64_substep<true, true, true, DBG>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0, cur, gsrc, wave);
+#pragma unroll
+        for (int q = 0; q < 8; q++) gsrc[q] += 64;
+    }
+    {   // stage ns - 2: nothing left to fetch; stage ns - 1: nothing left to read
+        unsigned char *cur = lds + (s & 1) * P64_SLOT, *nxt = lds + ((s + 1) & 1) * P64_SLOT;
+        pipe64_substep<false, false, true, DBG>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, gsrc, wave);
+        pipe64_substep<true, false, true, DBG>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0, cur, gsrc, wave);
+        pipe64_substep<false, false, true, DBG>(acc, fa[0], fb[0], fa[1], fb[1], nxt + a1, nxt + b1, cur, gsrc, wave);
+        pipe64_substep<false, false, false, DBG>(acc, fa[1], fb[1], fa[0], fb[0], nxt, nxt, cur, gsrc, wave);
+    }
+    if (DBG != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    if (g.wide_epilogue) {
+        __syncthreads();
+        epilogue_passes<EPI, 4, 8>(g, acc, (float *)(lds + wave * epi_pass_bytes(8)), m0 + wm * 64, n0 + wn * 128, lane);
+    } else {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            f32x4 part[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) part[i][j] = acc[i][half * 4 + j];
+            epilogue<EPI>(g, part, m0 + wm * 64, n0 + wn * 128 + half * 64, frow, fq);
+        }
+    }
+}
+
 static int gemm_variant() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("SGCLIP_GEMM_VARIANT");
-        v = e ? atoi(e) : 5;
+        v = e ? atoi(e) : 7;
     }
     return v;
 }
@@ -580,7 +739,18 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
     const int variant = gemm_variant();
     const bool use32 = variant == 2 || (variant >= 3 && g.K <= 1024);
     const long big_tiles = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) * splits;
-    if ((variant == 4 || (variant == 5 && big_tiles >= 512)) && g.M > 128 && g.K % 32 == 0 && g.N >= 256) {
+    if (variant >= 7 && big_tiles >= 512 && g.M > 128 && g.K % 64 == 0 && g.K >= 128 && g.N >= 256) {
+        g.tiles_m = ceil_div(g.M, 256);
+        g.tiles_n = ceil_div(g.N, 256);
+        auto go = [&](auto kernel) {
+            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P64_SLOT);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)g.tiles_m * g.tiles_n, gy), dim3(512), 2 * P64_SLOT, stream, g);
+        };
+        if (EPI == SGCLIP_EPI_BIAS_BF16 && g.debug_mode == 1) go(gemm_pipe64_kernel<SGCLIP_EPI_BIAS_BF16, 1>);
+        else if (EPI == SGCLIP_EPI_BIAS_BF16 && g.debug_mode == 3) go(gemm_pipe64_kernel<SGCLIP_EPI_BIAS_BF16, 3>);
+        else if (EPI == SGCLIP_EPI_BIAS_BF16 && g.debug_mode == 4) go(gemm_pipe64_kernel<SGCLIP_EPI_BIAS_BF16, 4>);
+        else go(gemm_pipe64_kernel<EPI, 0>);
+    } else if ((variant == 4 || (variant >= 5 && big_tiles >= 512)) && g.M > 128 && g.K % 32 == 0 && g.N >= 256) {
         g.tiles_m = ceil_div(g.M, 256);
         g.tiles_n = ceil_div(g.N, 256);
         static bool attr_big = false;

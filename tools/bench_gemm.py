@@ -10,10 +10,16 @@ shapes = [("qkv", 2304, 768, _lib.EPI_BIAS_BF16), ("oproj", 768, 768, _lib.EPI_B
           ("fc1", 3072, 768, _lib.EPI_BIAS_GELU_BF16), ("fc2", 768, 3072, _lib.EPI_BIAS_RESID_F32),
           ("patch", 768, 3072, _lib.EPI_F32), ("sq4096", 4096, 4096, _lib.EPI_BIAS_BF16)]
 torch.manual_seed(0)
+only = os.environ.get("ONLY")
 for name, N, K, epi in shapes:
+    if only and name not in only.split(","):
+        continue
     m = 4096 if name == "sq4096" else M
-    A = torch.randn(m, K, device=dev).to(torch.bfloat16)
-    W = (torch.randn(N, K, device=dev) * K ** -0.5).to(torch.bfloat16)
+    pad = int(os.environ.get("PAD", 0))   # extra elements in the leading dimensions of A and W
+    A = torch.randn(m, K + pad, device=dev).to(torch.bfloat16)[:, :K]
+    W = (torch.randn(N, K + pad, device=dev) * K ** -0.5).to(torch.bfloat16)[:, :K]
+    if os.environ.get("ZERO"):   # all-zero operands: same cycles, much less switching power -> shows clock throttling
+        A.zero_(); W.zero_()
     bias = torch.randn(N, device=dev)
     out = torch.zeros(m, N, device=dev, dtype=torch.float32 if epi in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_F32) else torch.bfloat16)
     for _ in range(3):
