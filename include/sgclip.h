@@ -238,6 +238,15 @@ int sgclip_attention(const void *qkv_dev, void *out_dev, int n_seq, int T, int h
  * (class token / end-of-text token) reaches the output (modeling_clip.py:650-651, 574-581). */
 int sgclip_attention_pooled(const void *qkv_dev, const int32_t *q_rows_dev, void *out_dev, int n_seq, int T,
                             int heads, int causal, const int32_t *key_mask_dev, void *stream);
+/* Fused q/k/v projection + attention of one encoder layer, for unmasked sequences of T <= 128 tokens
+ * (CLIPAttention.forward, modeling_clip.py:298-335, minus its out_proj): x bf16 [n_seq*T, d] (the
+ * layer-norm output, row stride ldx), w_qkv bf16 [3d, d] (q, k, v rows stacked, row stride ldw),
+ * bias f32 [3d]; out bf16 [n_seq*T, d] = concat_heads(softmax(q k^T / 8) v).  Same result as
+ * sgclip_gemm_bf16(BIAS_BF16) followed by sgclip_attention, without the [rows, 3d] activation in HBM.
+ * sgclip_qkv_attention_supported says whether (T, heads) is in range (1 = yes).                   */
+int sgclip_qkv_attention_supported(int T, int heads);
+int sgclip_qkv_attention(const void *x_dev, int ldx, const void *w_qkv_dev, int ldw, const float *bias_dev,
+                         void *out_dev, int n_seq, int T, int heads, void *stream);
 
 /* ------------------------------------------------------------------------
  * (6) Adjoints of the kernels above, for the train step

@@ -12,12 +12,11 @@
 // 4 KiB LDS tile and read back with ds_read_b64_tr_b16.
 // Q, K fragments are 16-byte loads straight from global memory (each 128-byte
 // head row is one cache line, fully consumed by the wave).
-#include "common.h"
+#include "tile_common.h"
 
 namespace sgclip {
 
 constexpr int ATT_WAVES = 4;
-constexpr float NEG_BIG = -1.0e30f;
 
 struct AttnArgs {
     const bf16_t *qkv;
@@ -29,58 +28,6 @@ struct AttnArgs {
     int q_tiles;  // ceil(T / 32)
     long long n_items;  // n_seq * heads
 };
-
-// One key block of the online softmax, in the base-2 domain (scores * 0.125 * log2 e).
-// st: S^T accumulators of this lane's query (register g = key n0 + (g&3) + 8*(g>>2) + 4*h); on
-// return pb holds exp2(score - running max) as the bf16 B operand of O^T += V^T * P^T.
-// MASKED = false is the interior-block path: every key valid, no comparisons.
-// The output accumulators are rescaled only when some lane's running maximum moved.
-template <bool MASKED>
-__device__ __forceinline__ void online_softmax_step(f32x16 &st, float &m_run, float &l_run, f32x16 &o0, f32x16 &o1,
-                                                    bf16x8 (&pb)[2], int n0, int m, int h, int T, bool causal,
-                                                    const int32_t *kmask) {
-    constexpr float C = 0.125f * 1.4426950408889634f;
-    float mx = NEG_BIG;
-#pragma unroll
-    for (int g = 0; g < 16; g++) {
-        float t = st[g] * C;
-        if (MASKED) {
-            const int n = n0 + (g & 3) + 8 * (g >> 2) + 4 * h;
-            bool ok = n < T;
-            if (causal) ok = ok && (n <= m);
-            if (kmask) ok = ok && (kmask[min(n, T - 1)] != 0);
-            t = ok ? t : NEG_BIG;
-        }
-        st[g] = t;
-        mx = fmaxf(mx, t);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    float psum = 0.f;
-#pragma unroll
-    for (int g = 0; g < 16; g++) {
-        float p = __builtin_amdgcn_exp2f(st[g] - m_new);
-        if (MASKED) p = st[g] > 0.5f * NEG_BIG ? p : 0.f;   // a row with no valid key yet has m_new == NEG_BIG
-        st[g] = p;
-        psum += p;
-    }
-    psum += __shfl_xor(psum, 32, 64);
-    if (__ballot(m_new != m_run)) {
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            o0[g] *= alpha;
-            o1[g] *= alpha;
-        }
-        m_run = m_new;
-    }
-    l_run += psum;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; s2++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) pb[s2][j] = (bf16_t)st[8 * s2 + j];
-}
 
 __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t vlds[ATT_WAVES][32 * 64];

@@ -17,7 +17,7 @@
 // Small problems (M <= 128) use the 128 x 128, 4-wave, 2-slot kernel.
 // Epilogues fuse bias, quick-GELU, the fp32 residual add and the patch-embedding
 // row remap + position embedding.
-#include "common.h"
+#include "tile_common.h"
 
 #include <stdlib.h>
 
@@ -42,9 +42,6 @@ struct GemmArgs {
     int debug_mode;     // diagnostics only: 1 = skip epilogue stores, 2 = single K step
 };
 
-// byte offset of 16-byte chunk `c` (0..7) of tile row `row` in the swizzled LDS image
-__device__ __forceinline__ int lds_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
-
 // one 1 KiB piece (8 rows x 128 B) of an operand tile: lane -> (row, swizzled chunk)
 __device__ __forceinline__ void stage_piece(const bf16_t *__restrict__ G, int ld, int row0, int max_row, int k0,
                                             unsigned char *lds_tile, int piece, int lane) {
@@ -59,13 +56,6 @@ __device__ __forceinline__ void stage_piece(const bf16_t *__restrict__ G, int ld
 // x * sigmoid(1.702 x) with the hardware exp2 / rcp (relative error ~1e-6, far below bf16 output rounding)
 __device__ __forceinline__ float quick_gelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x));
-}
-
-// XCD-aware remap: blocks that share an XCD (same blockIdx % 8) walk neighbouring
-// tiles of one A row panel, so the panel stays in that XCD's L2.  Bijective for any grid.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
 // split-K launches: workgroup row blockIdx.y owns K range [y * g.K, min((y + 1) * g.K, k_total))
@@ -561,10 +551,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmArgs g) {
         }
     }
 }
-
-#define SG_MFMA 0x008
-#define SG_VMEM_RD 0x020
-#define SG_DS_RD 0x100
 
 // ---------------------------------------------------------------------------
 // 256 x 256 tile, 64-deep stages: every DMA piece is 8 rows x 128 contiguous bytes, a whole

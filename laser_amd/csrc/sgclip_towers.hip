@@ -128,6 +128,15 @@ static int vit_chunk() {
     return v;
 }
 
+static bool fused_qkv_attention() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SGCLIP_FUSED_QKV_ATTN");   // 0 = separate kernels (A/B measurements)
+        v = e ? atoi(e) : 1;
+    }
+    return v != 0;
+}
+
 static bool build_layout(const sgclip_tower_desc_t *t, Layout &L) {
     if (!t || t->hidden <= 0 || t->hidden % 64 != 0 || t->heads * 64 != t->hidden || t->ffn % 64 != 0 ||
         t->layers <= 0 || t->tokens <= 0 || t->proj <= 0 || t->hidden > 1024) {
@@ -231,13 +240,24 @@ static int run_layers(const sgclip_tower_desc_t *t, const TowerPtrs &P, const Wo
                       const int32_t *key_mask, void *stream) {
     const int d = t->hidden, f = t->ffn, M = seqs * T;
     const int last = t->layers - 1;
+    // short unmasked sequences in bulk (the image towers at T = 50): q/k/v projection and attention in one kernel,
+    // attention output into the front of `big` (the layer-norm output in `h` is its input)
+    const bool fused = fused_qkv_attention() && !causal && !key_mask && sgclip_qkv_attention_supported(T, t->heads) &&
+                       (long long)ceil_div(seqs, 256 / T) * t->heads >= 512;
     for (int l = 0; l < last; l++) {
         CHECK(sgclip_layernorm(w.x, d, nullptr, M, d, P.F(SGCLIP_T_LN1_W, l), P.F(SGCLIP_T_LN1_B, l), t->ln_eps,
                                SGCLIP_DTYPE_BF16, w.h, stream));
-        CHECK(sgclip_gemm_bf16(w.h, d, P.B(SGCLIP_T_QKV_W, l), d, w.big, 3 * d, M, 3 * d, d, SGCLIP_EPI_BIAS_BF16,
-                               P.F(SGCLIP_T_QKV_B, l), nullptr, 0, stream));
-        CHECK(sgclip_attention(w.big, w.h, seqs, T, t->heads, causal, key_mask, stream));
-        CHECK(sgclip_gemm_bf16(w.h, d, P.B(SGCLIP_T_O_W, l), d, w.x, d, M, d, d, SGCLIP_EPI_BIAS_RESID_F32,
+        const bf16_t *attn_out = w.h;
+        if (fused) {
+            CHECK(sgclip_qkv_attention(w.h, d, P.B(SGCLIP_T_QKV_W, l), d, P.F(SGCLIP_T_QKV_B, l), w.big, seqs, T, t->heads,
+                                       stream));
+            attn_out = w.big;
+        } else {
+            CHECK(sgclip_gemm_bf16(w.h, d, P.B(SGCLIP_T_QKV_W, l), d, w.big, 3 * d, M, 3 * d, d, SGCLIP_EPI_BIAS_BF16,
+                                   P.F(SGCLIP_T_QKV_B, l), nullptr, 0, stream));
+            CHECK(sgclip_attention(w.big, w.h, seqs, T, t->heads, causal, key_mask, stream));
+        }
+        CHECK(sgclip_gemm_bf16(attn_out, d, P.B(SGCLIP_T_O_W, l), d, w.x, d, M, d, d, SGCLIP_EPI_BIAS_RESID_F32,
                                P.F(SGCLIP_T_O_B, l), nullptr, 0, stream));
         CHECK(sgclip_layernorm(w.x, d, nullptr, M, d, P.F(SGCLIP_T_LN2_W, l), P.F(SGCLIP_T_LN2_B, l), t->ln_eps,
                                SGCLIP_DTYPE_BF16, w.h, stream));

@@ -1,0 +1,77 @@
+// Helpers shared by the tiled MFMA kernels (GEMM, attention, fused QKV + attention).
+#pragma once
+#include "common.h"
+
+namespace sgclip {
+
+// sched_group_barrier instruction classes
+#define SG_MFMA 0x008
+#define SG_VMEM_RD 0x020
+#define SG_DS_RD 0x100
+
+// byte offset of 16-byte chunk `c` (0..7) of tile row `row` in a swizzled LDS image of 128-byte rows:
+// ds_read_b128 of 16 consecutive rows x one chunk index touches every bank group once
+__device__ __forceinline__ int lds_off(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+
+// XCD-aware remap: blocks that share an XCD (same blockIdx % 8) walk neighbouring
+// tiles of one A row panel, so the panel stays in that XCD's L2.  Bijective for any grid.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+constexpr float NEG_BIG = -1.0e30f;
+
+// One key block of the online softmax, in the base-2 domain (scores * 0.125 * log2 e).
+// st: S^T accumulators of this lane's query (register g = key n0 + (g&3) + 8*(g>>2) + 4*h); on
+// return pb holds exp2(score - running max) as the bf16 B operand of O^T += V^T * P^T.
+// MASKED = false is the interior-block path: every key valid, no comparisons.
+// The output accumulators are rescaled only when some lane's running maximum moved.
+template <bool MASKED>
+__device__ __forceinline__ void online_softmax_step(f32x16 &st, float &m_run, float &l_run, f32x16 &o0, f32x16 &o1,
+                                                    bf16x8 (&pb)[2], int n0, int m, int h, int T, bool causal,
+                                                    const int32_t *kmask) {
+    constexpr float C = 0.125f * 1.4426950408889634f;
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        float t = st[g] * C;
+        if (MASKED) {
+            const int n = n0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            bool ok = n < T;
+            if (causal) ok = ok && (n <= m);
+            if (kmask) ok = ok && (kmask[min(n, T - 1)] != 0);
+            t = ok ? t : NEG_BIG;
+        }
+        st[g] = t;
+        mx = fmaxf(mx, t);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    float psum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        float p = __builtin_amdgcn_exp2f(st[g] - m_new);
+        if (MASKED) p = st[g] > 0.5f * NEG_BIG ? p : 0.f;   // a row with no valid key yet has m_new == NEG_BIG
+        st[g] = p;
+        psum += p;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    if (__ballot(m_new != m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            o0[g] *= alpha;
+            o1[g] *= alpha;
+        }
+        m_run = m_new;
+    }
+    l_run += psum;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) pb[s2][j] = (bf16_t)st[8 * s2 + j];
+}
+
+}  // namespace sgclip

@@ -295,6 +295,15 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, out
     return y
 
 
+def qkv_attention(x: torch.Tensor, w_qkv: torch.Tensor, bias: torch.Tensor, n_seq: int, T: int, heads: int):
+    """Fused q/k/v projection + attention: x bf16 [n_seq*T, d], w_qkv bf16 [3d, d], bias f32 [3d] -> bf16 [n_seq*T, d]."""
+    lib = _lib.load()
+    out = torch.empty((n_seq * T, heads * 64), dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.sgclip_qkv_attention(x.data_ptr(), x.stride(0), w_qkv.data_ptr(), w_qkv.stride(0), bias.data_ptr(),
+                                        out.data_ptr(), n_seq, T, heads, _stream()))
+    return out
+
+
 def attention(qkv: torch.Tensor, n_seq: int, T: int, heads: int, causal: bool, key_mask: Optional[torch.Tensor] = None):
     lib = _lib.load()
     out = torch.empty((n_seq * T, heads * 64), dtype=torch.bfloat16, device=qkv.device)

@@ -147,6 +147,34 @@ def test_attention_pooled_equals_the_full_kernel_rows(dev, n_seq, T, heads, caus
     assert torch.equal(got, full[rows.long().to(dev)])
 
 
+@pytest.mark.parametrize("n_seq,T,heads", [(5, 50, 12), (23, 50, 4), (1, 50, 2), (7, 37, 3), (4, 64, 2), (3, 100, 2),
+                                           (6, 128, 2), (300, 50, 12)])
+def test_fused_qkv_attention_equals_the_separate_kernels(dev, n_seq, T, heads):
+    """sgclip_qkv_attention against sgclip_gemm_bf16(BIAS_BF16) + sgclip_attention and against fp32 torch."""
+    d = heads * 64
+    x = _rand_bf16((n_seq * T, d), dev, 1.0, seed=T + heads)
+    w = _rand_bf16((3 * d, d), dev, d ** -0.5, seed=n_seq)
+    bias = torch.randn(3 * d, generator=torch.Generator().manual_seed(3)).to(dev)
+    got = ops.qkv_attention(x, w, bias, n_seq, T, heads)
+    qkv = torch.empty((n_seq * T, 3 * d), dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16(x, w, qkv, _lib.EPI_BIAS_BF16, bias=bias)
+    sep = ops.attention(qkv, n_seq, T, heads, False, None)
+    torch.cuda.synchronize()
+    # both round q, k, v to bf16 before the attention; only the summation order inside the GEMM differs
+    assert (got.float() - sep.float()).abs().max().item() < 2e-2
+    ref = _attn_ref((x.float() @ w.float().t() + bias).to(torch.bfloat16), n_seq, T, heads, False, None)
+    assert (got.float() - ref).abs().max().item() < 3e-2
+
+
+def test_fused_qkv_attention_rejects_what_it_does_not_cover(dev):
+    lib = _lib.load()
+    assert lib.sgclip_qkv_attention_supported(50, 12) == 1
+    assert lib.sgclip_qkv_attention_supported(577, 16) == 0
+    x = _rand_bf16((577, 128), dev)
+    rc = lib.sgclip_qkv_attention(x.data_ptr(), 128, x.data_ptr(), 128, x.data_ptr(), x.data_ptr(), 1, 577, 2, None)
+    assert rc == _lib.EINVAL
+
+
 def test_attention_exact_integers(dev):
     """Small-integer q/k/v with one-hot softmax rows: checks the fragment maps exactly."""
     n_seq, T, heads = 2, 50, 2

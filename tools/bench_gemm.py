@@ -33,3 +33,20 @@ for name, N, K, epi in shapes:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print(f"{name:8s} M={m} N={N} K={K}: {ms*1e3:8.1f} us  {2.0*m*N*K/ms/1e9:7.1f} TFLOP/s", flush=True)
+
+if not only or "qkvattn" in only.split(","):
+    n_seq, T, heads = M // 50, 50, 12
+    d = heads * 64
+    x = torch.randn(n_seq * T, d, device=dev).to(torch.bfloat16)
+    w = (torch.randn(3 * d, d, device=dev) * d ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(3 * d, device=dev)
+    for _ in range(3):
+        ops.qkv_attention(x, w, bias, n_seq, T, heads)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.qkv_attention(x, w, bias, n_seq, T, heads)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f"qkvattn  rows={n_seq*T} d={d}: {ms*1e3:8.1f} us  {2.0*n_seq*T*3*d*d/ms/1e9:7.1f} TFLOP/s (GEMM flops only)", flush=True)
