@@ -136,8 +136,9 @@ def pmc_traffic(substr):
     if not os.path.exists(path):
         return None
     ks = json.load(open(path))["kernels"]
-    tot = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for k, v in ks.items() if substr in k)
-    n = sum(v["launches"] for k, v in ks.items() if substr in k)
+    subs = (substr,) if isinstance(substr, str) else tuple(substr)
+    tot = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for k, v in ks.items() if any(s in k for s in subs))
+    n = sum(v["launches"] for k, v in ks.items() if any(s in k for s in subs))
     return tot / n if n else None
 
 
@@ -302,9 +303,10 @@ def main():
                    "text_positions_run": [t[2] for t in plan.tokens], "parallelism": f"dp{world} (clips)"},
         "frames_per_s": world * args.frames * args.steps / elapsed,
         "clip_latency_ms": ms_per_step,
-        "roofline": {"kernel": "sgclip::gemm_kernel (bf16 MFMA GEMMs of the three ViT towers + text towers, all epilogues)",
+        "roofline": {"kernel": "sgclip::gemm_*_kernel + sgclip::qkv_attn_kernel (bf16 MFMA GEMMs of the three ViT towers + text "
+                               "towers with all epilogues; the q/k/v GEMM carries the fused attention)",
                      "bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": gemm_tflops / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic("gemm"),
+                     "frac": gemm_tflops / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(("gemm", "qkv_attn")),
                      "algorithmic_flops_per_launch": g_fl / max(g_n, 1),
                      "launches_per_step": g_n / tsteps, "avg_launch_ms": g_ms / max(g_n, 1)},
         "roofline_crop": {"kernel": "sgclip::crop_kernel", "bound": "hbm", "achieved": crop_gbs, "peak": HBM_PEAK_GBS,
