@@ -256,6 +256,13 @@ int sgclip_qkv_attention(const void *x_dev, int ldx, const void *w_qkv_dev, int 
  * sgclip_gemm_bf16 with transposed operands; these entry points supply the
  * transposes, reductions and the non-GEMM adjoints.
  * ---------------------------------------------------------------------- */
+/* C f32 [M, N] += A^T B for A bf16 [Kd, M] (row stride lda) and B bf16 [Kd, N] (ldb), both row major with the
+ * reduction index as the row: the weight gradient dW = dY^T X of a linear layer (torch.autograd's
+ * grad of nn.Linear reached from loss.backward(), scripts/train_sgclip.py:884) straight from the
+ * activations, no transposed copies.  M, N multiples of 8; the reduction is split over workgroups
+ * that add atomically, so repeated calls accumulate (the caller zeroes C once). */
+int sgclip_gemm_tn_bf16(const void *A_dev, int lda, const void *B_dev, int ldb, float *C_dev, int ldc, int M, int N,
+                        int Kd, void *stream);
 /* out[c][r] = in[r][c], bf16; in [rows, cols] (ld_in), out [cols, ld_out], ld_out >= rows,
  * columns rows..ld_out-1 zero-filled (pads the reduction dimension of a weight gradient). */
 int sgclip_transpose_bf16(const void *in_dev, int64_t ld_in, int rows, int cols, void *out_dev, int64_t ld_out,

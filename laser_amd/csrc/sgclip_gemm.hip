@@ -20,6 +20,7 @@
 #include "tile_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -148,6 +149,15 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs &g, const f32x4 (&ac
 #pragma unroll
             for (int e = 0; e < 4; e++) region[(i * 16 + fq * 4 + e) * EPI_LD + j * 16 + frow] = acc[i][j][e];
     __syncthreads();
+    if constexpr (EPI == SGCLIP_EPI_F32_ATOMIC) {
+        // one dword per lane, 256 contiguous bytes of one row per instruction: the shape atomics run at full rate in
+#pragma unroll 4
+        for (int row = 0; row < 64; row++) {
+            const int m = mw + row, n = nw + lane;
+            if (m < g.M && n < g.N) unsafeAtomicAdd((float *)g.C + (size_t)m * g.ldc + n, region[row * EPI_LD + lane]);
+        }
+        return;
+    }
     const int c4 = (lane & 15) * 4, r0 = lane >> 4;
     const int n = nw + c4;
     if (n >= g.N) return;  // N is a multiple of 4 wherever this epilogue is used
@@ -336,6 +346,31 @@ template <int EPI, int NI, int NJ>
 __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (&acc)[NI][NJ], float *region, int mw, int nw,
                                                 int lane) {
     constexpr int LDW = NJ * 16 + 4;
+    if constexpr (EPI == SGCLIP_EPI_F32_ATOMIC) {
+        // Atomic adds run at full rate only when a wave instruction covers contiguous bytes (one dword per lane,
+        // 256 bytes of one row); with four columns per lane every 64-byte request would carry 16 useful bytes.
+        const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) region[(fq * 4 + e) * LDW + j * 16 + frow] = acc[i][j][e];
+            wave_lds_sync();
+#pragma unroll 4
+            for (int row = 0; row < 16; row++) {
+                const int m = mw + i * 16 + row;
+#pragma unroll
+                for (int cb = 0; cb < NJ * 16; cb += 64) {
+                    const int n = nw + cb + lane;
+                    const float v = region[row * LDW + cb + lane];
+                    if (m < g.M && n < g.N) unsafeAtomicAdd((float *)g.C + (size_t)m * g.ldc + n, v);
+                }
+            }
+            wave_lds_sync();
+        }
+        return;
+    }
     constexpr bool BF = EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16;
     constexpr int CPL = BF ? 8 : 4;                // columns per lane
     constexpr int LPR = NJ * 16 / CPL;             // lanes per row
@@ -707,6 +742,185 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// C_f32[M, N] += A^T B for A bf16 [Kd, M] and B bf16 [Kd, N], both ROW major (the reduction index is
+// the row): the weight gradient dW = dY^T X straight from the activations as they lie in memory, no
+// transposed copies.  256 x 256 tile, 64 reduction rows per stage, the pipeline of gemm_pipe64_kernel.
+// An operand stage is [64 rows][256 columns] (512 B per row) in LDS; the MFMA fragments (8 reduction
+// steps of one column per lane) are read TRANSPOSED with ds_read_b64_tr_b16: the 16 lanes of a
+// fragment quarter fetch a 4 row x 16 column block, 8 bytes each, and every lane receives one column
+// of it.  16-byte chunk c of row r sits at chunk c ^ swz(r), swz(r) = 2 * ((r & 3) | ((r >> 3) & 1) << 2):
+// the 8 rows x 2 chunks a 32-lane read group touches then fall on 16 different bank groups.
+// The reduction is split over blockIdx.y; every workgroup adds its tile with fp32 atomics.
+// Rows past Kd are fetched from a zero block, columns past M / N are clamped (computed, not stored).
+// ---------------------------------------------------------------------------
+static __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ int tn_swz(int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); }
+
+template <bool SYNC, bool DMA, bool READ>
+__device__ __forceinline__ void tn_substep(f32x4 (&acc)[4][8], const bf16x8 (&ca)[4], const bf16x8 (&cb)[8],
+                                           bf16x8 (&na)[4], bf16x8 (&nb)[8], const unsigned char *rd_row, int a_x, int b_x,
+                                           unsigned char *wr_slot, const unsigned (&goff)[8], const unsigned char *abase,
+                                           const unsigned char *bbase, const unsigned char *zero, unsigned row_lim, int wave) {
+    if (SYNC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (DMA) {
+        // rows at or past row_lim (the reduction rows left in this workgroup's range) read zeros
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned row = 2u * (unsigned)(wave + 8 * (q & 3)) + ((unsigned)threadIdx.x >> 5 & 1u);
+            const unsigned char *src = (q < 4 ? abase : bbase) + goff[q];
+            src = row < row_lim ? src : zero;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(wr_slot + (wave + 8 * q) * 1024), 16, 0, 0);
+        }
+    }
+    if (READ) {
+        // rd_row: this lane's row 8 fq + tq of the sub-step (+ its 8-byte half); 4 rows further = + 2048 bytes, same swizzle.
+        // Fragment i / j starts 16 columns = two 16-byte chunks further: chunk bits 1.. of the swizzled offset flip.
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const unsigned char *p = rd_row + (a_x ^ (i << 5));
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)p);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(p + 2048));
+            na[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const unsigned char *p = rd_row + 32768 + (b_x ^ (j << 5));
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)p);
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(p + 2048));
+            nb[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+    if (DMA) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_VMEM_RD, 1, 0);
+        }
+    }
+    if (READ) {
+#pragma unroll
+        for (int q = 0; q < 24; q++) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DS_RD, 1, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 rows x 128 columns of C
+    const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x - tm * g.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+    // reduction range of this workgroup: g.K rows from blockIdx.y * g.K (a multiple of 64), cut at k_total
+    const int k_begin = blockIdx.y * g.K;
+    const int k_len = min(g.K, g.k_total - k_begin);
+    const int ns = max(2, (k_len + 63) / 64);   // a second stage of zeros when the range is that short
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[2][4], fb[2][8];
+
+    // DMA piece p (32 per operand and stage) = stage rows 2p, 2p + 1; lane -> row 2p + (lane >> 5), LDS chunk position
+    // lane & 31, which holds source chunk (lane & 31) ^ swz(row).  q < 4: A pieces wave + 8 q; q >= 4: B pieces.
+    unsigned goff[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const bool isb = q >= 4;
+        const int row = 2 * (wave + 8 * (q & 3)) + (lane >> 5);
+        const int c = (lane & 31) ^ tn_swz(row);
+        const int col0 = (isb ? n0 : m0) + c * 8;
+        const int lim = isb ? g.N : g.M;                     // multiples of 8
+        const int col = col0 < lim ? col0 : lim - 8;         // past the matrix: any valid chunk (never stored)
+        goff[q] = ((unsigned)row * (unsigned)(isb ? g.ldw : g.lda) + (unsigned)col) * 2u;
+    }
+    const unsigned char *abase = (const unsigned char *)(g.A + (size_t)k_begin * g.lda);
+    const unsigned char *bbase = (const unsigned char *)(g.W + (size_t)k_begin * g.ldw);
+    const unsigned char *zero = (const unsigned char *)g_zero16;
+    const unsigned astep = 64u * (unsigned)g.lda * 2u, bstep = 64u * (unsigned)g.ldw * 2u;
+
+    // fragment reads: lane = (fq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3) fetches row 8 fq + tq, columns 4 tp .. + 3
+    const int fq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int frow = 8 * fq + tq;
+    const int row_off = frow * 512 + (tp & 1) * 8;
+    const int a_x = (((wm * 8 + (tp >> 1)) ^ tn_swz(frow)) << 4);
+    const int b_x = (((wn * 16 + (tp >> 1)) ^ tn_swz(frow)) << 4);
+
+    // stages 0 and 1
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const unsigned lim = (unsigned)max(0, min(64, k_len - 64 * t));
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const unsigned row = 2u * (unsigned)(wave + 8 * (q & 3)) + ((unsigned)lane >> 5);
+            const unsigned char *src = (q < 4 ? abase + t * astep : bbase + t * bstep) + goff[q];
+            src = row < lim ? src : zero;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds + t * P64_SLOT + (wave + 8 * q) * 1024), 16, 0, 0);
+        }
+    }
+    abase += 2 * (size_t)astep;
+    bbase += 2 * (size_t)bstep;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // fragments of stage 0, sub-step 0
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned char *p = lds + row_off + (a_x ^ (i << 5));
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)p);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(p + 2048));
+        fa[0][i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const unsigned char *p = lds + row_off + 32768 + (b_x ^ (j << 5));
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)p);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(p + 2048));
+        fb[0][j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+
+    // sub-step 1 of a stage reads rows 32.. of the same slot: + 32 * 512 bytes
+    int s = 0;
+    for (; s < ns - 2; s++) {
+        unsigned char *cur = lds + (s & 1) * P64_SLOT, *nxt = lds + ((s + 1) & 1) * P64_SLOT;
+        const unsigned lim = (unsigned)max(0, min(64, k_len - 64 * (s + 2)));
+        tn_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
+                                       zero, lim, wave);
+        tn_substep<true, true, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + row_off, a_x, b_x, cur, goff, abase, bbase, zero, lim,
+                                     wave);
+        abase += astep;
+        bbase += bstep;
+    }
+    {
+        unsigned char *cur = lds + (s & 1) * P64_SLOT, *nxt = lds + ((s + 1) & 1) * P64_SLOT;
+        tn_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
+                                       zero, 0u, wave);
+        tn_substep<true, false, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + row_off, a_x, b_x, cur, goff, abase, bbase, zero, 0u,
+                                      wave);
+        tn_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], nxt + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
+                                       zero, 0u, wave);
+        tn_substep<false, false, false>(acc, fa[1], fb[1], fa[0], fb[0], nxt, a_x, b_x, cur, goff, abase, bbase, zero, 0u, wave);
+    }
+    __syncthreads();
+    epilogue_passes<SGCLIP_EPI_F32_ATOMIC, 4, 8>(g, acc, (float *)(lds + wave * epi_pass_bytes(8)), m0 + wm * 64, n0 + wn * 128,
+                                                  lane);
+}
+
 static int gemm_variant() {
     static int v = -1;
     if (v < 0) {
@@ -849,4 +1063,52 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
         default: set_error("sgclip_gemm_bf16: unknown epilogue %d", epilogue); return SGCLIP_EINVAL;
     }
     return launch_check("sgclip_gemm_bf16");
+}
+
+extern "C" int sgclip_gemm_tn_bf16(const void *A_dev, int lda, const void *B_dev, int ldb, float *C_dev, int ldc, int M, int N,
+                                   int Kd, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (M == 0 || N == 0 || Kd == 0) return SGCLIP_OK;
+    if (!A_dev || !B_dev || !C_dev || M < 0 || N < 0 || Kd < 0 || (M & 7) || (N & 7) || lda < M || ldb < N || ldc < N) {
+        set_error("sgclip_gemm_tn_bf16: bad shape M=%d N=%d Kd=%d lda=%d ldb=%d ldc=%d (M, N multiples of 8)", M, N, Kd, lda,
+                  ldb, ldc);
+        return SGCLIP_EINVAL;
+    }
+    if (((uintptr_t)A_dev & 15) || ((uintptr_t)B_dev & 15) || ((uintptr_t)C_dev & 3) || (lda & 7) || (ldb & 7) ||
+        (size_t)64 * lda * 2 + (size_t)M * 2 >= (1ull << 32) || (size_t)64 * ldb * 2 + (size_t)N * 2 >= (1ull << 32)) {
+        set_error("sgclip_gemm_tn_bf16: A/B must be 16-byte aligned with leading dimensions a multiple of 8");
+        return SGCLIP_EINVAL;
+    }
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t *)A_dev;
+    g.W = (const bf16_t *)B_dev;
+    g.C = C_dev;
+    g.lda = lda;
+    g.ldw = ldb;
+    g.ldc = ldc;
+    g.M = M;
+    g.N = N;
+    g.k_total = Kd;
+    g.tiles_m = ceil_div(M, 256);
+    g.tiles_n = ceil_div(N, 256);
+    // reduction slices: about one workgroup per CU, each at least 512 rows deep
+    static int target = -1;
+    if (target < 0) {
+        const char *e = getenv("SGCLIP_TN_WGS");
+        target = e ? atoi(e) : 256;
+    }
+    const long tiles = (long)g.tiles_m * g.tiles_n;
+    int splits = (int)std::max(1L, std::min((long)ceil_div(Kd, 512), target / tiles));
+    const int kc = ceil_div(ceil_div(Kd, splits), 64) * 64;
+    splits = ceil_div(Kd, kc);
+    g.K = kc;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P64_SLOT);
+        attr = true;
+    }
+    KernelTimer timer(TK_GEMM0 + SGCLIP_EPI_F32_ATOMIC, 2.0 * M * N * Kd, stream);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(512), 2 * P64_SLOT, stream, g);
+    return launch_check("sgclip_gemm_tn_bf16");
 }

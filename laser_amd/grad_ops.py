@@ -5,6 +5,7 @@ train step's backward pass is one of the calls below (or `ops.gemm_bf16`).
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -21,6 +22,9 @@ def _dtype_code(t: torch.Tensor) -> int:
     if t.dtype == F32:
         return _lib.DTYPE_F32
     raise TypeError(f"expected bf16 or f32, got {t.dtype}")
+
+
+_TN_WGRAD = os.environ.get("SGCLIP_TN_WGRAD", "1") != "0"   # 0: transposed copies + the NT kernel (comparison)
 
 
 def pad64(n: int) -> int:
@@ -194,10 +198,16 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] 
     to a multiple of 64.  The reduction over M (all tokens of the batch) is split over workgroups that add into
     `out` atomically, so repeated calls accumulate."""
     M = dy.shape[0]
-    Mp = pad64(M)
-    dyt = transpose_bf16(dy, Mp)
-    xt = transpose_bf16(x, Mp)
     if out is None:
         out = torch.zeros((dy.shape[1], x.shape[1]), dtype=F32, device=dy.device)
     assert out.dtype == F32 and out.shape == (dy.shape[1], x.shape[1]) and out.stride(1) == 1
+    if _TN_WGRAD and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 \
+            and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
+        # both operands as they lie in memory (rows = the reduction index); fragments are transposed on the LDS read
+        _lib.check(_lib.load().sgclip_gemm_tn_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
+                                                   out.stride(0), dy.shape[1], x.shape[1], M, _stream()))
+        return out
+    Mp = pad64(M)
+    dyt = transpose_bf16(dy, Mp)
+    xt = transpose_bf16(x, Mp)
     return gemm_bf16(dyt, xt, out, _lib.EPI_F32_ATOMIC)

@@ -83,6 +83,36 @@ def test_gemm_split_k_accumulates_atomically(dev, M, N, K):
     assert (out.double() - ref).abs().max().item() <= 2e-3 * K ** 0.5
 
 
+@pytest.mark.parametrize("Kd,M,N", [(64, 256, 256), (128, 16, 8), (51200, 768, 768), (6400, 2304, 768), (1425, 520, 264),
+                                    (37, 64, 128), (1000, 3072, 768), (4099, 768, 3072)])
+def test_gemm_tn_accumulates_a_transposed_product(dev, Kd, M, N):
+    """sgclip_gemm_tn_bf16: C += A^T B from row-major operands, any reduction length, partial tiles, strided rows."""
+    a = _randn((Kd, M + 8), dev, 61, 1.0, torch.bfloat16)[:, :M]
+    b = _randn((Kd, N), dev, 62, 1.0, torch.bfloat16)
+    c0 = _randn((M, N), dev, 63, 1.0)
+    c = c0.clone()
+    from laser_amd import _lib
+    from laser_amd.ops import _stream
+    _lib.check(_lib.load().sgclip_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), c.stride(0),
+                                               M, N, Kd, _stream()))
+    torch.cuda.synchronize()
+    want = c0.double() + a.double().t() @ b.double()
+    assert ((c.double() - want).abs().max() / want.abs().max()).item() <= 2e-5
+
+
+def test_gemm_tn_exact_small_integers(dev):
+    """Integer operands: every product and sum is exact in fp32, so the fragment maps are checked bit for bit."""
+    g = torch.Generator().manual_seed(4)
+    a = torch.randint(-3, 4, (200, 264), generator=g).to(torch.bfloat16).to(dev)
+    b = torch.randint(-3, 4, (200, 520), generator=g).to(torch.bfloat16).to(dev)
+    c = torch.zeros((264, 520), dtype=torch.float32, device=dev)
+    from laser_amd import _lib
+    from laser_amd.ops import _stream
+    _lib.check(_lib.load().sgclip_gemm_tn_bf16(a.data_ptr(), 264, b.data_ptr(), 520, c.data_ptr(), 520, 264, 520, 200, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(c, a.float().t() @ b.float())
+
+
 @pytest.mark.parametrize("M,out_f,in_f", [(6400, 768, 768), (850, 3072, 768), (100, 64, 128)])
 def test_linear_wgrad(dev, M, out_f, in_f):
     dy = _randn((M, out_f), dev, 53, 1.0, torch.bfloat16)

@@ -1,4 +1,2 @@
-for d in 0 1 2; do
-  echo "qkvattn debug $d"
-  SGCLIP_QKVATTN_DEBUG=$d M=262144 ONLY=qkvattn timeout -k 10 100 python tools/bench_gemm.py || exit 1
-done
+for t in 64 128 256; do echo "TN target $t"; SGCLIP_TN_WGS=$t timeout -k 10 100 python tools/bench_gemm_tn.py 2>&1 | grep -v amdgpu.ids || exit 1; done
+echo "KD 12800 target 256"; KD=12800 timeout -k 10 100 python tools/bench_gemm_tn.py 2>&1 | grep -v amdgpu.ids
