@@ -128,6 +128,42 @@ def test_vit_l14_336_towers_match_oracle():
     print(f"L/14-336: image feature rel err {rel:.2e}, text feature rel err {trel:.2e}")
 
 
+def test_vit_b32_tower_in_bulk_matches_oracle():
+    """A batch large enough (1 300 crops) for the bulk kernels of the B/32 image tower, the 256 x 256 pipelined GEMM and
+    the fused q/k/v + attention kernel, which the small clips above do not reach: features of sampled crops against the
+    fp32 oracle, and every crop against the same tower run in small batches (the small-grid kernels)."""
+    from laser_amd import _lib, ops
+    from laser_amd.weights import random_state_dict
+    from laser_amd.predicate_model import CROP_DTYPE
+    from oracle import clip_ref, resample_ref
+    cfg = config_by_name("vit-b-32")
+    sd = random_state_dict(cfg, 23)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(8)
+    H, W, n = 240, 320, 1300
+    frame = (rng.integers(0, 256, size=(H, W, 3)) // 2 + np.linspace(0, 127, W)[None, :, None]).astype(np.uint8)
+    x1 = rng.integers(0, W - 40, n); y1 = rng.integers(0, H - 40, n)
+    x2 = np.minimum(W, x1 + rng.integers(20, 200, n)); y2 = np.minimum(H, y1 + rng.integers(20, 200, n))
+    rows = [(0, -1, -1, W, H, int(a), int(b), int(c), int(d), _lib.CROP_PLAIN, 0) for a, b, c, d in zip(x1, y1, x2, y2)]
+    frames_t = torch.from_numpy(ops.pad_bytes(frame)).to(dev)
+    patches = ops.crop_preprocess(frames_t, None, np.array(rows, dtype=CROP_DTYPE), 224, layout=_lib.LAYOUT_PATCHES,
+                                  patch=32, out_dtype=_lib.DTYPE_BF16)
+    tower = ops.Tower(cfg, "vision", sd, dev)
+    got = tower.encode_images(patches, n)
+    P = cfg.n_patches
+    small = torch.cat([tower.encode_images(patches[i * P:(i + 100) * P], min(100, n - i)) for i in range(0, n, 100)])
+    torch.cuda.synchronize()
+    rel_small = ((got - small).norm(dim=-1) / small.norm(dim=-1)).max().item()
+    assert rel_small < 5e-3, rel_small
+    pick = [0, 1, 249, 250, 251, 777, 1298, 1299]       # incl. both sides of a 5-sequence row tile and the ragged last tile
+    px = torch.from_numpy(np.stack([resample_ref.preprocess(frame[y1[i]:y2[i], x1[i]:x2[i]], 224) for i in pick]))
+    torch.set_num_threads(16)
+    want = clip_ref.image_features(sd, cfg, px)
+    rel = ((got[pick].cpu() - want).norm(dim=-1) / want.norm(dim=-1)).max().item()
+    assert rel < 1e-2, rel
+    print(f"B/32 bulk tower: rel err vs oracle {rel:.2e}, vs small batches {rel_small:.2e}")
+
+
 @pytest.mark.parametrize("seed", [101, 102, 103])
 def test_forward_input_variants_vs_oracle(seed):
     """Seeded variations of the argument forms the reference accepts (list / tuple / ndarray boxes,
