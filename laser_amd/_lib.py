@@ -124,6 +124,10 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build the HIP extension first "
                                f"(python -c 'import __graft_entry__ as g; g.build()' or make -C laser_amd/csrc)")
+        # torch ships its own HIP runtime (torch/lib/libamdhip64.so).  The process must hold ONE runtime: the one that
+        # owns torch's device memory and streams has to be loaded before this library resolves its libamdhip64
+        # dependency, or the kernels register with a second runtime that sees no device.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
