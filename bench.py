@@ -104,8 +104,19 @@ class ClipPlan:
             self.algo_crop_bytes += float(((3 + m) * wh + 2 * 3 * cfg.image * cfg.image).sum())
 
 
-def score_clip(model: PredicateModel, plan: ClipPlan):
-    """The device pipeline of PredicateModel.forward for one clip (inference path)."""
+_SIDE = {}
+
+
+def _side_streams(device):
+    if device not in _SIDE:
+        _SIDE[device] = [torch.cuda.Stream(device=device) for _ in range(3)]
+    return _SIDE[device]
+
+
+def score_clip(model: PredicateModel, plan: ClipPlan, concurrent: bool = True):
+    """The device pipeline of PredicateModel.forward for one clip (inference path).  The three image towers are
+    independent until the similarity step: the unary tower and the two halves of the pair tower run on side streams, so
+    that the tails and kernel boundaries of one launch sequence are filled by the others (BENCH_STREAMS=0: one stream)."""
     towers = model._packed()
     cfg = model.cfg
     (cv, ct, cs), (uv, ut, us), (bv, bt, bs) = (towers[p] for p in ("clip_cate_model", "clip_unary_model", "clip_binary_model"))
@@ -113,13 +124,36 @@ def score_clip(model: PredicateModel, plan: ClipPlan):
     tf_u = ut.encode_text(*plan.tokens[1])
     tf_b = bt.encode_text(*plan.tokens[2])
     kw = dict(layout=_lib.LAYOUT_PATCHES, patch=cfg.patch, out_dtype=_lib.DTYPE_BF16, entries_dev_ready=True)
-    po = ops.crop_preprocess(plan.di.frames, plan.di.masks, plan.obj_table, cfg.image, out=plan.obj_patches,
-                             entries_dev=plan.obj_dev, **kw)
-    cf = cv.encode_images(po, plan.n_obj)
-    uf = uv.encode_images(po, plan.n_obj)
-    pp = ops.crop_preprocess(plan.di.frames, plan.di.masks, plan.pair_table, cfg.image, out=plan.pair_patches,
-                             entries_dev=plan.pair_dev, **kw)
-    pf = bv.encode_images(pp, plan.n_pair)
+    if not concurrent or os.environ.get("BENCH_STREAMS", "1") == "0":
+        po = ops.crop_preprocess(plan.di.frames, plan.di.masks, plan.obj_table, cfg.image, out=plan.obj_patches,
+                                 entries_dev=plan.obj_dev, **kw)
+        cf = cv.encode_images(po, plan.n_obj)
+        uf = uv.encode_images(po, plan.n_obj)
+        pp = ops.crop_preprocess(plan.di.frames, plan.di.masks, plan.pair_table, cfg.image, out=plan.pair_patches,
+                                 entries_dev=plan.pair_dev, **kw)
+        pf = bv.encode_images(pp, plan.n_pair)
+    else:
+        main = torch.cuda.current_stream()
+        s_un, s_p0, s_p1 = _side_streams(plan.obj_patches.device)
+        P = cfg.n_patches
+        s_p0.wait_stream(main)
+        with torch.cuda.stream(s_p0):
+            pp = ops.crop_preprocess(plan.di.frames, plan.di.masks, plan.pair_table, cfg.image, out=plan.pair_patches,
+                                     entries_dev=plan.pair_dev, **kw)
+            pf = torch.empty((plan.n_pair, cfg.proj), dtype=torch.float32, device=pp.device)
+            half = plan.n_pair // 2
+            s_p1.wait_stream(s_p0)
+            bv.encode_images(pp[: half * P], half, out=pf[:half], ws_slot=0)
+        with torch.cuda.stream(s_p1):
+            bv.encode_images(pp[half * P:], plan.n_pair - half, out=pf[half:], ws_slot=1)
+        po = ops.crop_preprocess(plan.di.frames, plan.di.masks, plan.obj_table, cfg.image, out=plan.obj_patches,
+                                 entries_dev=plan.obj_dev, **kw)
+        s_un.wait_stream(main)
+        with torch.cuda.stream(s_un):
+            uf = uv.encode_images(po, plan.n_obj)
+        cf = cv.encode_images(po, plan.n_obj)
+        for st in (s_un, s_p0, s_p1):
+            main.wait_stream(st)
     cate = ops.similarity(tf_c, cf, cs, _lib.SIM_SOFTMAX)
     unary = ops.similarity(tf_u, uf, us, _lib.SIM_SOFTMAX)
     binary = ops.similarity(tf_b, pf, bs, _lib.SIM_SOFTMAX)
@@ -283,7 +317,7 @@ def main():
     _lib.check(lib.sgclip_timing_enable(1, 4096))
     tsteps = min(args.steps, 2)
     for _ in range(tsteps):
-        step()
+        score_clip(model, plan, concurrent=False)   # one stream: a launch's events then bracket that kernel alone
     torch.cuda.synchronize()
     kinds = {k: timing_read(k) for k in (0, 1, 2, 3, 8, 9)}
     _lib.check(lib.sgclip_timing_enable(0, 0))

@@ -174,17 +174,20 @@ class Tower:
             put(L.T_FC2_B, i, sd[f"{b}.mlp.fc2.bias"])
         self.wb = wb.to(self.device)
         self.wf = wf.to(self.device)
-        self._ws: Optional[torch.Tensor] = None
+        self._ws: Dict[int, torch.Tensor] = {}
 
-    def _workspace(self, nbytes: int) -> torch.Tensor:
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._ws
+    def _workspace(self, nbytes: int, slot: int = 0) -> torch.Tensor:
+        ws = self._ws.get(slot)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[slot] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return ws
 
-    def encode_images(self, patches: torch.Tensor, n_images: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def encode_images(self, patches: torch.Tensor, n_images: int, out: Optional[torch.Tensor] = None,
+                      ws_slot: int = 0) -> torch.Tensor:
+        """ws_slot: calls that run concurrently on different streams need different workspaces."""
         lib = _lib.load()
         need = lib.sgclip_vit_workspace_bytes(C.byref(self.desc), n_images)
-        ws = self._workspace(max(need, 256))
+        ws = self._workspace(max(need, 256), ws_slot)
         if out is None:
             out = torch.empty((n_images, self.cfg.proj), dtype=torch.float32, device=self.device)
         _lib.check(lib.sgclip_vit_encode(C.byref(self.desc), self.wb.data_ptr(), self.wf.data_ptr(), patches.data_ptr(),

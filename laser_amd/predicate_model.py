@@ -12,6 +12,8 @@ There is no CPU fallback: without the HIP library or a GPU, construction fails.
 """
 from __future__ import annotations
 
+import os
+
 import functools
 import warnings
 from typing import Dict, List, Optional, Sequence
@@ -271,6 +273,16 @@ class PredicateModel(nn.Module):
         return ops.crop_preprocess(dev_in.frames, dev_in.masks, table, cfg.image, layout=_lib.LAYOUT_PATCHES,
                                    patch=cfg.patch, out_dtype=_lib.DTYPE_BF16, alpha=alpha, white_alpha=white_alpha)
 
+    def _side_streams(self):
+        """Three side HIP streams for the inference path: the image towers are independent until the similarity
+        step, so the unary tower and the two halves of the pair tower are queued beside the category tower; the
+        tails and kernel boundaries of one launch sequence are then filled by the others.
+        SGCLIP_CONCURRENT_TOWERS=0 keeps everything on the caller's stream."""
+        if getattr(self, "_streams", None) is None:
+            on = os.environ.get("SGCLIP_CONCURRENT_TOWERS", "1") != "0"
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)] if on else []
+        return self._streams
+
     def _encode_images(self, prefix: str, patches: torch.Tensor, n: int) -> torch.Tensor:
         if self._grad_mode():
             return training.encode_images(self._trainers()[prefix][0], patches, n)
@@ -318,6 +330,10 @@ class PredicateModel(nn.Module):
         if device_inputs is None:
             device_inputs = self.stage_inputs(batched_videos, batched_masks)
         di = device_inputs
+        side = [] if grad_mode else self._side_streams()
+        main_stream = torch.cuda.current_stream(self.device)
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(main_stream)     # frames and masks are in HBM: side streams start from here
         if batched_bboxes is None:                       # bit-packed masks: boxes come from the unpack kernel
             batched_bboxes = di.bbox_dicts()
         obj_index = {}                                   # (vid, fid, oid) -> position in batched_object_ids
@@ -357,8 +373,18 @@ class PredicateModel(nn.Module):
         cate_feat = unary_feat = None
         if n_obj:
             patches = self._crops(di, obj_table, alpha, white_alpha)
-            cate_feat = self._encode_images("clip_cate_model", patches, n_obj)
-            unary_feat = self._encode_images("clip_unary_model", patches, n_obj)
+            if side:
+                s_un = side[0]
+                s_un.wait_stream(main_stream)
+                with torch.cuda.stream(s_un):
+                    unary_feat = self._encode_images("clip_unary_model", patches, n_obj)
+                patches.record_stream(s_un)
+                cate_feat = self._encode_images("clip_cate_model", patches, n_obj)
+                main_stream.wait_stream(s_un)
+                unary_feat.record_stream(main_stream)
+            else:
+                cate_feat = self._encode_images("clip_cate_model", patches, n_obj)
+                unary_feat = self._encode_images("clip_unary_model", patches, n_obj)
         sim_mode = _lib.SIM_LOGIT if output_logit else _lib.SIM_SOFTMAX
 
         cate_out: Dict[int, object] = {v: {} for v in range(B)}
@@ -472,8 +498,28 @@ class PredicateModel(nn.Module):
         n_pair = len(pair_table)
         pair_feat = None
         if n_pair:
-            ppatches = self._crops(di, pair_table, alpha, white_alpha)
-            pair_feat = self._encode_images("clip_binary_model", ppatches, n_pair)
+            if side and n_pair >= 1024:
+                # queued from the point where the inputs were staged, not behind the object towers
+                s_p0, s_p1 = side[1], side[2]
+                P = self.cfg.n_patches
+                half = n_pair // 2
+                tower = self._packed()["clip_binary_model"][0]
+                s_p0.wait_event(inputs_ready)
+                with torch.cuda.stream(s_p0):
+                    ppatches = self._crops(di, pair_table, alpha, white_alpha)
+                    pair_feat = torch.empty((n_pair, self.cfg.proj), dtype=torch.float32, device=ppatches.device)
+                    s_p1.wait_stream(s_p0)
+                    tower.encode_images(ppatches[: half * P], half, out=pair_feat[:half], ws_slot=0)
+                with torch.cuda.stream(s_p1):
+                    tower.encode_images(ppatches[half * P:], n_pair - half, out=pair_feat[half:], ws_slot=1)
+                ppatches.record_stream(s_p1)
+                pair_feat.record_stream(s_p1)
+                pair_feat.record_stream(main_stream)
+                main_stream.wait_stream(s_p0)
+                main_stream.wait_stream(s_p1)
+            else:
+                ppatches = self._crops(di, pair_table, alpha, white_alpha)
+                pair_feat = self._encode_images("clip_binary_model", ppatches, n_pair)
 
         binary_out: List[object] = []
         pair_feats_out: Dict[int, object] = {v: torch.tensor([]) for v in range(B)}
