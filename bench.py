@@ -107,10 +107,11 @@ class ClipPlan:
 _SIDE = {}
 
 
-def _side_streams(device):
-    if device not in _SIDE:
-        _SIDE[device] = [torch.cuda.Stream(device=device) for _ in range(3)]
-    return _SIDE[device]
+def _side_streams(device, n=3):
+    have = _SIDE.setdefault(device, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
 
 
 def score_clip(model: PredicateModel, plan: ClipPlan, concurrent: bool = True):
@@ -134,25 +135,30 @@ def score_clip(model: PredicateModel, plan: ClipPlan, concurrent: bool = True):
         pf = bv.encode_images(pp, plan.n_pair)
     else:
         main = torch.cuda.current_stream()
-        s_un, s_p0, s_p1 = _side_streams(plan.obj_patches.device)
+        nsplit = int(os.environ.get("BENCH_PAIR_SPLITS", "2"))
+        streams = _side_streams(plan.obj_patches.device, 1 + nsplit)
+        s_un, s_pair = streams[0], streams[1:]
         P = cfg.n_patches
-        s_p0.wait_stream(main)
-        with torch.cuda.stream(s_p0):
+        s_pair[0].wait_stream(main)
+        with torch.cuda.stream(s_pair[0]):
             pp = ops.crop_preprocess(plan.di.frames, plan.di.masks, plan.pair_table, cfg.image, out=plan.pair_patches,
                                      entries_dev=plan.pair_dev, **kw)
             pf = torch.empty((plan.n_pair, cfg.proj), dtype=torch.float32, device=pp.device)
-            half = plan.n_pair // 2
-            s_p1.wait_stream(s_p0)
-            bv.encode_images(pp[: half * P], half, out=pf[:half], ws_slot=0)
-        with torch.cuda.stream(s_p1):
-            bv.encode_images(pp[half * P:], plan.n_pair - half, out=pf[half:], ws_slot=1)
+        bounds = [plan.n_pair * i // nsplit for i in range(nsplit + 1)]
+        for i, st in enumerate(s_pair):
+            if i:
+                st.wait_stream(s_pair[0])
+        for i, st in enumerate(s_pair):
+            with torch.cuda.stream(st):
+                a, b = bounds[i], bounds[i + 1]
+                bv.encode_images(pp[a * P: b * P], b - a, out=pf[a:b], ws_slot=i)
         po = ops.crop_preprocess(plan.di.frames, plan.di.masks, plan.obj_table, cfg.image, out=plan.obj_patches,
                                  entries_dev=plan.obj_dev, **kw)
         s_un.wait_stream(main)
         with torch.cuda.stream(s_un):
             uf = uv.encode_images(po, plan.n_obj)
         cf = cv.encode_images(po, plan.n_obj)
-        for st in (s_un, s_p0, s_p1):
+        for st in streams:
             main.wait_stream(st)
     cate = ops.similarity(tf_c, cf, cs, _lib.SIM_SOFTMAX)
     unary = ops.similarity(tf_u, uf, us, _lib.SIM_SOFTMAX)
@@ -346,7 +352,10 @@ def main():
                      "bound": "mfma", "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": gemm_tflops / MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(("gemm", "qkv_attn")),
                      "algorithmic_flops_per_launch": g_fl / max(g_n, 1),
-                     "launches_per_step": g_n / tsteps, "avg_launch_ms": g_ms / max(g_n, 1)},
+                     "launches_per_step": g_n / tsteps, "avg_launch_ms": g_ms / max(g_n, 1),
+                     "note": "launch durations from HIP events in a pass that queues the towers on ONE stream, so an "
+                             "event pair brackets its kernel alone (rocprof summary of that mode: BENCH_STREAMS=0); the "
+                             "timed steps behind `value` overlap the towers on four streams"},
         "roofline_crop": {"kernel": "sgclip::crop_kernel", "bound": "hbm", "achieved": crop_gbs, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": crop_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("crop_kernel"),
                           "algorithmic_bytes_per_launch": crop_bytes / max(crop_n, 1),
