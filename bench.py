@@ -121,11 +121,20 @@ def score_clip(model: PredicateModel, plan: ClipPlan, concurrent: bool = True):
     towers = model._packed()
     cfg = model.cfg
     (cv, ct, cs), (uv, ut, us), (bv, bt, bs) = (towers[p] for p in ("clip_cate_model", "clip_unary_model", "clip_binary_model"))
-    tf_c = ct.encode_text(*plan.tokens[0])
-    tf_u = ut.encode_text(*plan.tokens[1])
-    tf_b = bt.encode_text(*plan.tokens[2])
+    conc = concurrent and os.environ.get("BENCH_STREAMS", "1") != "0"
+    if conc:   # the text towers (small launches, needed only at the similarity step) on a side stream of their own
+        s_txt = _side_streams(plan.obj_patches.device, 4)[3]
+        s_txt.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_txt):
+            tf_c = ct.encode_text(*plan.tokens[0])
+            tf_u = ut.encode_text(*plan.tokens[1])
+            tf_b = bt.encode_text(*plan.tokens[2])
+    else:
+        tf_c = ct.encode_text(*plan.tokens[0])
+        tf_u = ut.encode_text(*plan.tokens[1])
+        tf_b = bt.encode_text(*plan.tokens[2])
     kw = dict(layout=_lib.LAYOUT_PATCHES, patch=cfg.patch, out_dtype=_lib.DTYPE_BF16, entries_dev_ready=True)
-    if not concurrent or os.environ.get("BENCH_STREAMS", "1") == "0":
+    if not conc:
         po = ops.crop_preprocess(plan.di.frames, plan.di.masks, plan.obj_table, cfg.image, out=plan.obj_patches,
                                  entries_dev=plan.obj_dev, **kw)
         cf = cv.encode_images(po, plan.n_obj)
@@ -136,8 +145,9 @@ def score_clip(model: PredicateModel, plan: ClipPlan, concurrent: bool = True):
     else:
         main = torch.cuda.current_stream()
         nsplit = int(os.environ.get("BENCH_PAIR_SPLITS", "2"))
-        streams = _side_streams(plan.obj_patches.device, 1 + nsplit)
-        s_un, s_pair = streams[0], streams[1:]
+        streams = _side_streams(plan.obj_patches.device, 4 + nsplit)
+        s_un, s_pair = streams[0], streams[4:]
+        streams = [s_un, streams[3]] + s_pair
         P = cfg.n_patches
         s_pair[0].wait_stream(main)
         with torch.cuda.stream(s_pair[0]):
