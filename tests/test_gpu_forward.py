@@ -164,6 +164,30 @@ def test_vit_b32_tower_in_bulk_matches_oracle():
     print(f"B/32 bulk tower: rel err vs oracle {rel:.2e}, vs small batches {rel_small:.2e}")
 
 
+def test_concurrent_towers_give_the_single_stream_result():
+    """forward() queues the unary tower and the halves of a large pair set on side streams; the result must be the
+    bits of the single-stream call, twice in a row (the second call reuses every workspace and stream)."""
+    from laser_amd.synthetic import make_clip_batch
+    cfg = config_by_name("tiny")
+    sd = predicate_model_state_dict(cfg, 31, float(np.log(100.0)))
+    tok = HashTokenizer(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    model = PredicateModel(None, None, "cuda:0", "tiny", tokenizer=tok).eval()
+    model.load_state_dict(sd)
+    b = make_clip_batch(9, n_videos=1, frames=5, objects=16, H=96, W=128, k_cate=5, k_unary=6, k_binary=4,
+                        min_box=12, max_box=90)
+    kw = b.forward_kwargs()
+    assert len(kw["batched_obj_pairs"]) >= 1024
+    assert len(model._side_streams()) == 3
+    runs = [model(**kw) for _ in range(2)]
+    model._streams = []                       # single stream
+    ref = model(**kw)
+    torch.cuda.synchronize()
+    for got in runs:
+        for g, w in ((got[0][0], ref[0][0]), (got[1][0], ref[1][0]), (got[2][0], ref[2][0])):
+            assert list(g.keys()) == list(w.keys())
+            assert torch.equal(g.values_tensor(), w.values_tensor())
+
+
 @pytest.mark.parametrize("seed", [101, 102, 103])
 def test_forward_input_variants_vs_oracle(seed):
     """Seeded variations of the argument forms the reference accepts (list / tuple / ndarray boxes,
