@@ -23,6 +23,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 namespace sgclip {
 
@@ -921,6 +923,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmArgs g) {
                                                   lane);
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel instead of before every launch
+static void lds_attr_once(const void *fn, int bytes) {
+    static std::mutex mu;
+    static std::vector<const void *> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (std::find(done.begin(), done.end(), fn) != done.end()) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.push_back(fn);
+}
+
 static int gemm_variant() {
     static int v = -1;
     if (v < 0) {
@@ -943,7 +955,7 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
         g.tiles_m = ceil_div(g.M, 256);
         g.tiles_n = ceil_div(g.N, 256);
         auto go = [&](auto kernel) {
-            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P64_SLOT);
+            lds_attr_once((const void *)kernel, 2 * P64_SLOT);
             hipLaunchKernelGGL(kernel, dim3((unsigned)g.tiles_m * g.tiles_n, gy), dim3(512), 2 * P64_SLOT, stream, g);
         };
         if (EPI == SGCLIP_EPI_BIAS_BF16 && g.debug_mode == 1) go(gemm_pipe64_kernel<SGCLIP_EPI_BIAS_BF16, 1>);
