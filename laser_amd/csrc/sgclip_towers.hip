@@ -235,9 +235,10 @@ static Work carve(const sgclip_tower_desc_t *t, void *base, int64_t seqs, int64_
 
 // Only the pooled token of every sequence (w.rows) leaves the tower, so the last layer computes
 // keys and values for all rows but attention output, out-projection and the MLP for those rows
-// alone; the result is the pooled rows' residual stream in w.xp.
+// alone; the result is the pooled rows' residual stream in w.xp.  pooled_first: the pooled row is row 0 of every
+// sequence (image towers), which lets the last layer's query projection run on those rows alone.
 static int run_layers(const sgclip_tower_desc_t *t, const TowerPtrs &P, const Work &w, int seqs, int T, int causal,
-                      const int32_t *key_mask, void *stream) {
+                      const int32_t *key_mask, bool pooled_first, void *stream) {
     const int d = t->hidden, f = t->ffn, M = seqs * T;
     const int last = t->layers - 1;
     // short unmasked sequences in bulk (the image towers at T = 50): q/k/v projection and attention in one kernel,
@@ -271,8 +272,16 @@ static int run_layers(const sgclip_tower_desc_t *t, const TowerPtrs &P, const Wo
         hipStream_t hs = (hipStream_t)stream;
         CHECK(sgclip_layernorm(w.x, d, nullptr, M, d, P.F(SGCLIP_T_LN1_W, l), P.F(SGCLIP_T_LN1_B, l), t->ln_eps,
                                SGCLIP_DTYPE_BF16, w.h, stream));
-        CHECK(sgclip_gemm_bf16(w.h, d, P.B(SGCLIP_T_QKV_W, l), d, w.big, 3 * d, M, 3 * d, d, SGCLIP_EPI_BIAS_BF16,
-                               P.F(SGCLIP_T_QKV_B, l), nullptr, 0, stream));
+        if (pooled_first) {
+            // keys and values of every row, queries of the pooled rows only (row 0 of every sequence: strided operands)
+            CHECK(sgclip_gemm_bf16(w.h, d, P.B(SGCLIP_T_QKV_W, l) + (size_t)d * d, d, w.big + d, 3 * d, M, 2 * d, d,
+                                   SGCLIP_EPI_BIAS_BF16, P.F(SGCLIP_T_QKV_B, l) + d, nullptr, 0, stream));
+            CHECK(sgclip_gemm_bf16(w.h, T * d, P.B(SGCLIP_T_QKV_W, l), d, w.big, T * 3 * d, seqs, d, d, SGCLIP_EPI_BIAS_BF16,
+                                   P.F(SGCLIP_T_QKV_B, l), nullptr, 0, stream));
+        } else {
+            CHECK(sgclip_gemm_bf16(w.h, d, P.B(SGCLIP_T_QKV_W, l), d, w.big, 3 * d, M, 3 * d, d, SGCLIP_EPI_BIAS_BF16,
+                                   P.F(SGCLIP_T_QKV_B, l), nullptr, 0, stream));
+        }
         CHECK(sgclip_attention_pooled(w.big, w.rows, w.hp, seqs, T, t->heads, causal, key_mask, stream));
         hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)seqs), dim3(128), 0, hs, w.x, w.rows, w.xp, d / 4);
         CHECK(launch_check("gather_rows_kernel"));
@@ -402,7 +411,7 @@ extern "C" int sgclip_vit_encode(const sgclip_tower_desc_t *desc, const void *w_
                                SGCLIP_DTYPE_F32, w.x, stream));
         hipLaunchKernelGGL(first_rows_kernel, dim3(ceil_div(nc, 256)), dim3(256), 0, hs, nc, T, w.rows);
         CHECK(launch_check("first_rows_kernel"));
-        CHECK(run_layers(desc, Pp, w, nc, T, 0, nullptr, stream));
+        CHECK(run_layers(desc, Pp, w, nc, T, 0, nullptr, true, stream));
         CHECK(sgclip_layernorm(w.xp, d, nullptr, nc, d, Pp.F(SGCLIP_T_POST_LN_W), Pp.F(SGCLIP_T_POST_LN_B),
                                desc->ln_eps, SGCLIP_DTYPE_F32, w.pooled, stream));
         CHECK(sgclip_linear_f32(w.pooled, Pp.F(SGCLIP_T_PROJ_W), nc, E, d, out_dev + (size_t)i0 * E, stream));
@@ -445,7 +454,7 @@ extern "C" int sgclip_text_encode(const sgclip_tower_desc_t *desc, const void *w
     hipLaunchKernelGGL(eos_rows_kernel, dim3(ceil_div(n_texts, 64)), dim3(64), 0, hs, ids_dev, n_texts, T, desc->eos_id,
                        w.rows);
     CHECK(launch_check("text_embed_kernel"));
-    CHECK(run_layers(desc, Pp, w, n_texts, T, 1, attn_mask_dev, stream));
+    CHECK(run_layers(desc, Pp, w, n_texts, T, 1, attn_mask_dev, false, stream));
     CHECK(sgclip_layernorm(w.xp, d, nullptr, n_texts, d, Pp.F(SGCLIP_T_POST_LN_W), Pp.F(SGCLIP_T_POST_LN_B), desc->ln_eps,
                            SGCLIP_DTYPE_F32, w.pooled, stream));
     CHECK(sgclip_linear_f32(w.pooled, Pp.F(SGCLIP_T_PROJ_W), n_texts, E, d, out_dev, stream));
