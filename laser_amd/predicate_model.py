@@ -202,7 +202,10 @@ class PredicateModel(nn.Module):
     def _drop_stale_packed_weights(self):
         """Called once per forward(): an optimizer step or an in-place edit of a parameter since the
         blobs were packed bumps its version counter."""
-        versions = tuple(p._version for p in self.parameters())
+        plist = getattr(self, "_param_tuple", None)
+        if plist is None:          # the Parameter objects never change identity; walking the module tree costs milliseconds
+            plist = self._param_tuple = tuple(self.parameters())
+        versions = tuple(p._version for p in plist)
         if versions != getattr(self, "_packed_versions", None):
             self.invalidate_packed_weights()
             self._packed_versions = versions
@@ -550,7 +553,7 @@ class PredicateModel(nn.Module):
             b_rows = [(r, nm) for r, nm in enumerate(bkws) if nm != dummy_str]
             binary_out.append(ProbDict(dense, b_rows, cols, lambda fp, nm: (fp[0], fp[1], nm), "row_major"))
 
-        dummy_prob = torch.stack(dummy_terms).sum() if dummy_terms else torch.tensor(0.0, device=dev)
+        dummy_prob = torch.stack(dummy_terms).sum() if dummy_terms else torch.zeros((), dtype=torch.float32, device=dev)   # a fill, not a blocking copy
         if output_embeddings:
             emb = {"cate_obj_clip_features": cate_feats_out, "cate_object_ids": ids_lookup,
                    "unary_obj_clip_features": unary_feats_out, "unary_object_ids": ids_lookup,
