@@ -730,7 +730,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64_kernel(GemmArgs g) {
     }
     if (g.wide_epilogue) {
         __syncthreads();
-        epilogue_passes<EPI, 4, 8>(g, acc, (float *)(lds + wave * epi_pass_bytes(8)), m0 + wm * 64, n0 + wn * 128, lane);
+        // debug_mode 9 (diagnostic, wrong results): every tile stores to rows 0..255, which stay in L2 -- the epilogue
+        // without its HBM traffic
+        epilogue_passes<EPI, 4, 8>(g, acc, (float *)(lds + wave * epi_pass_bytes(8)), (g.debug_mode == 9 ? 0 : m0) + wm * 64,
+                                   n0 + wn * 128, lane);
     } else {
 #pragma unroll
         for (int half = 0; half < 2; half++) {
