@@ -954,7 +954,12 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
     const int variant = gemm_variant();
     const bool use32 = variant == 2 || (variant >= 3 && g.K <= 1024);
     const long big_tiles = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) * splits;
-    if (variant >= 7 && big_tiles >= 512 && g.M > 128 && g.K % 64 == 0 && g.K >= 128 && g.N >= 256) {
+    static int min_tiles = -1;   // 256 x 256 tiles from this many on (smaller grids: 256 x 128 tiles, two workgroups per CU)
+    if (min_tiles < 0) {
+        const char *e = getenv("SGCLIP_PIPE64_MIN_TILES");
+        min_tiles = e ? atoi(e) : 256;
+    }
+    if (variant >= 7 && big_tiles >= min_tiles && g.M > 128 && g.K % 64 == 0 && g.K >= 128 && g.N >= 256) {
         g.tiles_m = ceil_div(g.M, 256);
         g.tiles_n = ceil_div(g.N, 256);
         auto go = [&](auto kernel) {
