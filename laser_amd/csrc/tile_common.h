@@ -33,28 +33,42 @@ __device__ __forceinline__ void online_softmax_step(f32x16 &st, float &m_run, fl
                                                     const int32_t *kmask) {
     constexpr float C = 0.125f * 1.4426950408889634f;
     float mx = NEG_BIG;
+    float m_new;
+    float psum = 0.f;
+    if (MASKED) {
 #pragma unroll
-    for (int g = 0; g < 16; g++) {
-        float t = st[g] * C;
-        if (MASKED) {
+        for (int g = 0; g < 16; g++) {
+            float t = st[g] * C;
             const int n = n0 + (g & 3) + 8 * (g >> 2) + 4 * h;
             bool ok = n < T;
             if (causal) ok = ok && (n <= m);
             if (kmask) ok = ok && (kmask[min(n, T - 1)] != 0);
             t = ok ? t : NEG_BIG;
+            st[g] = t;
+            mx = fmaxf(mx, t);
         }
-        st[g] = t;
-        mx = fmaxf(mx, t);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    float psum = 0.f;
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        m_new = fmaxf(m_run, mx);
 #pragma unroll
-    for (int g = 0; g < 16; g++) {
-        float p = __builtin_amdgcn_exp2f(st[g] - m_new);
-        if (MASKED) p = st[g] > 0.5f * NEG_BIG ? p : 0.f;   // a row with no valid key yet has m_new == NEG_BIG
-        st[g] = p;
-        psum += p;
+        for (int g = 0; g < 16; g++) {
+            float p = __builtin_amdgcn_exp2f(st[g] - m_new);
+            p = st[g] > 0.5f * NEG_BIG ? p : 0.f;   // a row with no valid key yet has m_new == NEG_BIG
+            st[g] = p;
+            psum += p;
+        }
+    } else {
+        // interior block: the maximum is taken on the raw scores (the scale is positive) and the scale rides in the
+        // exponent's fused multiply-add, one vector operation per score fewer
+#pragma unroll
+        for (int g = 0; g < 16; g++) mx = fmaxf(mx, st[g]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        m_new = fmaxf(m_run, mx * C);
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[g], C, -m_new));
+            st[g] = p;
+            psum += p;
+        }
     }
     psum += __shfl_xor(psum, 32, 64);
     if (__ballot(m_new != m_run)) {
