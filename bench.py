@@ -14,8 +14,10 @@ are resident in HBM when the timed region starts.  With N > 1 every rank scores
 its own clip (weak scaling, clips are independent) and the dense probability
 blocks are all-gathered over RCCL each step.
 
-Usage: python bench.py --gpus N --steps K --warmup W   (N > 1: launch with
-python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+Usage: python bench.py --gpus N --steps K --warmup W.  With N > 1 and no launcher environment
+(WORLD_SIZE unset) the script starts `python -m torch.distributed.run --nproc-per-node N` on itself,
+one process per GPU, as the reference's drivers spawn theirs (scripts/eval_sgclip.py:643); under a
+launcher it is one of the N ranks.
 """
 from __future__ import annotations
 
@@ -23,6 +25,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -54,9 +58,24 @@ def parse():
     ap.add_argument("--cpu-sample-pairs", type=int, default=240)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the all-gather even with one rank (rehearsal)")
-    ap.add_argument("--forward-api", action="store_true",
-                    help="also time PredicateModel.forward() from host numpy inputs (PCIe + host index build included)")
+    ap.add_argument("--no-forward-api", action="store_true",
+                    help="skip timing PredicateModel.forward() from host numpy inputs (PCIe + host index build included)")
+    ap.add_argument("--no-c4", action="store_true",
+                    help="skip the ViT-L/14-336 sub-result (1 frame x 64 objects x 4 032 pairs)")
+    ap.add_argument("--distinct-frames", type=int, default=0,
+                    help="frame pixel pool size (0 = every frame distinct, as the workload states)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start one process per GPU through torch.distributed.run and hand back its
+    exit code.  Runs before anything touches the GPU (a process that has initialised HIP must not be replaced)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 class ClipPlan:
@@ -263,14 +282,64 @@ def cpu_baseline(args, cfg, sd, tok, batch):
             "stage_seconds": {k: round(v, 3) for k, v in oracle.timers.items()}}
 
 
+def kernel_pass(model, plan, tsteps):
+    """Per-kernel durations, live, with HIP events on the launch stream: everything queued on ONE stream so that an
+    event pair brackets its kernel alone.  -> dict of (ms, launches, work) per timing kind, per `tsteps` steps."""
+    lib = _lib.load()
+    _lib.check(lib.sgclip_timing_enable(1, 65536))
+    for _ in range(tsteps):
+        score_clip(model, plan, concurrent=False)
+    torch.cuda.synchronize()
+    kinds = {k: timing_read(k) for k in (0, 1, 2, 3, 4, 8, 9)}
+    _lib.check(lib.sgclip_timing_enable(0, 0))
+    return kinds
+
+
+def c4_sub_result(device, tok_cls):
+    """BASELINE.json configs[3] on one GPU: ViT-L/14 at 336^2, one 1280 x 720 frame with 64 objects and all 4 032
+    ordered pairs (4 096 crops = 4 160 image encodes of 577 tokens), inputs resident in HBM."""
+    cfg = config_by_name("vit-l-14-336")
+    tok = tok_cls(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    model = PredicateModel(None, None, device, "vit-l-14-336", tokenizer=tok, init_seed=9).eval()
+    for p in ("clip_cate_model", "clip_unary_model", "clip_binary_model"):
+        model._modules[p].logit_scale.data.fill_(float(np.log(100.0)))
+    model.invalidate_packed_weights()
+    batch = make_clip_batch(300, n_videos=1, frames=1, objects=64)
+    plan = ClipPlan(model, batch, device)
+    score_clip(model, plan)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        score_clip(model, plan)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / n
+    kinds = kernel_pass(model, plan, 1)
+    g_ms = sum(kinds[k][0] for k in (0, 1, 2, 3, 4))
+    g_fl = sum(kinds[k][2] for k in (0, 1, 2, 3, 4))
+    a_ms, _, a_fl = kinds[9]
+    crops = plan.n_obj + plan.n_pair
+    out = {"workload": "1 frame x 64 objects x 4032 ordered pairs at 1280x720, 336^2 crops, 35 + 200 + 50 keywords, "
+                       "vit-l-14-336, random-init weights",
+           "ms_per_frame": ms, "crops_per_s": crops / (ms * 1e-3), "crops": crops,
+           "image_encodes": 2 * plan.n_obj + plan.n_pair,
+           "gemm_ms": g_ms, "gemm_tflops": g_fl / (g_ms * 1e-3) / 1e12 if g_ms else 0.0,
+           "attention_ms": a_ms, "attention_tflops": a_fl / (a_ms * 1e-3) / 1e12 if a_ms else 0.0,
+           "crop_ms": kinds[8][0], "crop_GBps": kinds[8][2] / (kinds[8][0] * 1e-3) / 1e9 if kinds[8][0] else 0.0,
+           "executed_tflops": (g_fl + a_fl) / (ms * 1e-3) / 1e12,
+           "note": "kernel times from a one-stream pass with HIP events; ms_per_frame with the towers on side streams"}
+    del model, plan
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.force_dist:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
@@ -289,8 +358,9 @@ def main():
     for p in ("clip_cate_model", "clip_unary_model", "clip_binary_model"):
         model._modules[p].logit_scale.data.fill_(float(np.log(100.0)))
     model.invalidate_packed_weights()
-    # every rank scores its own clip (different seed); frame pixels come from a pool of 4 distinct frames
-    batch = make_clip_batch(100 + rank, n_videos=1, frames=args.frames, objects=args.objects, distinct_frames=4)
+    # every rank scores its own clip (different seed); every frame has its own pixels unless --distinct-frames
+    batch = make_clip_batch(100 + rank, n_videos=1, frames=args.frames, objects=args.objects,
+                            distinct_frames=args.distinct_frames or None)
     plan = ClipPlan(model, batch, device)
     crops_per_step = plan.n_obj + plan.n_pair
     encodes_per_step = 2 * plan.n_obj + plan.n_pair
@@ -327,23 +397,17 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * crops_per_step * args.steps / elapsed
 
-    # per-kernel durations, live, with HIP events on the launch stream (separate pass so
-    # that event recording does not perturb the number above)
-    lib = _lib.load()
-    _lib.check(lib.sgclip_timing_enable(1, 4096))
+    # per-kernel durations in a separate pass, so that event recording does not perturb the number above
     tsteps = min(args.steps, 2)
-    for _ in range(tsteps):
-        score_clip(model, plan, concurrent=False)   # one stream: a launch's events then bracket that kernel alone
-    torch.cuda.synchronize()
-    kinds = {k: timing_read(k) for k in (0, 1, 2, 3, 8, 9)}
-    _lib.check(lib.sgclip_timing_enable(0, 0))
-    g_ms = sum(kinds[k][0] for k in (0, 1, 2, 3))
-    g_n = sum(kinds[k][1] for k in (0, 1, 2, 3))
-    g_fl = sum(kinds[k][2] for k in (0, 1, 2, 3))
+    kinds = kernel_pass(model, plan, tsteps)
+    g_ms = sum(kinds[k][0] for k in (0, 1, 2, 3, 4))
+    g_n = sum(kinds[k][1] for k in (0, 1, 2, 3, 4))
+    g_fl = sum(kinds[k][2] for k in (0, 1, 2, 3, 4))
     gemm_tflops = g_fl / (g_ms * 1e-3) / 1e12 if g_ms else 0.0
     crop_ms, crop_n, crop_bytes = kinds[8]
     crop_gbs = crop_bytes / (crop_ms * 1e-3) / 1e9 if crop_ms else 0.0
     step_ms_timed = {"gemm": g_ms / tsteps, "attention": kinds[9][0] / tsteps, "crop": crop_ms / tsteps}
+    executed_flops_per_step = (g_fl + kinds[9][2]) / tsteps
 
     result = {
         "metric": "object+pair crops scored/sec", "value": value, "unit": "crops/s", "n_gpus": world,
@@ -371,11 +435,15 @@ def main():
                           "algorithmic_bytes_per_launch": crop_bytes / max(crop_n, 1),
                           "avg_launch_ms": crop_ms / max(crop_n, 1), "algorithmic_bytes_per_step": plan.algo_crop_bytes},
         "kernel_ms_per_step": step_ms_timed,
-        "whole_step_tflops": encodes_per_step * cfg.vit_flops_per_encode() / (ms_per_step * 1e-3) / 1e12,
+        # FLOPs the kernels executed (GEMM + attention launches of all towers; the last layer runs on the pooled
+        # rows only, so this is below encodes x the reference's FLOPs per encode) over the timed step
+        "whole_step_tflops": executed_flops_per_step / (ms_per_step * 1e-3) / 1e12,
+        "executed_tflop_per_step": executed_flops_per_step / 1e12,
+        "reference_tflop_per_step": encodes_per_step * cfg.vit_flops_per_encode() / 1e12,
     }
     if rank == 0 and world == 1:
         result["calibration"] = calibrate(device)
-    if args.forward_api and world == 1:
+    if not args.no_forward_api and world == 1:
         kw = batch.forward_kwargs()
         model(**kw)
         torch.cuda.synchronize()
@@ -408,6 +476,8 @@ def main():
                                  "staged_inputs_ms": dt2 * 1e3, "staged_inputs_crops_per_s": crops_per_step / dt2,
                                  "note": "PredicateModel.forward(): host index build + lazy mappings; host_inputs also "
                                          "concatenates and uploads frames and masks over PCIe; text features cached (eval)"}
+    if rank == 0 and world == 1 and not args.no_c4:
+        result["c4_l14_336"] = c4_sub_result(device, HashTokenizer)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         result["cpu_baseline"] = cpu_baseline(args, cfg, sd, tok, batch)

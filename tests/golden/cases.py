@@ -5,9 +5,9 @@ from __future__ import annotations
 from laser_amd.synthetic import make_clip_batch
 
 
-def tiny_batch(seed, n_videos=2, frames=3, objects=4, H=150, W=200, train=False):
+def tiny_batch(seed, n_videos=2, frames=3, objects=4, H=150, W=200, train=False, max_box=140):
     b = make_clip_batch(seed, n_videos=n_videos, frames=frames, objects=objects, H=H, W=W,
-                        k_cate=5, k_unary=7, k_binary=6, min_box=12, max_box=140)
+                        k_cate=5, k_unary=7, k_binary=6, min_box=12, max_box=max_box)
     if train:
         names = b.batched_names[0]
         kws = b.batched_binary_kws[0]
@@ -17,6 +17,23 @@ def tiny_batch(seed, n_videos=2, frames=3, objects=4, H=150, W=200, train=False)
         ][:n_videos]
     return b
 
+
+def demo_clip_batch(seed, frames=8, objects=5, H=720, W=1280, k_cate=127, k_binary=57):
+    """The shape of the evaluation driver's call on one demo clip (scripts/eval_sgclip.py:332-352): 8 frames at
+    1280 x 720 with at most 5 masks each (an object may be missing from a frame), the dataset-wide category and
+    relation vocabularies (127 / 57 entries, laser/utils.py:28-215), no unary keywords, pairs given by the caller."""
+    import numpy as np
+    b = make_clip_batch(seed, n_videos=1, frames=frames, objects=objects, H=H, W=W, k_cate=k_cate, k_unary=1,
+                        k_binary=k_binary, min_box=24, max_box=640)
+    rng = np.random.default_rng(seed + 1000)
+    drop = {(f, o) for f in range(frames) for o in range(objects) if o >= 2 and rng.random() < 0.25}
+    keep = [i for i, (_, f, o) in enumerate(b.batched_object_ids) if (f, o) not in drop]
+    b.batched_masks = [b.batched_masks[i] for i in keep]
+    b.batched_bboxes = [b.batched_bboxes[i] for i in keep]
+    b.batched_object_ids = [b.batched_object_ids[i] for i in keep]
+    b.batched_obj_pairs = [p for p in b.batched_obj_pairs if (p[1], p[2][0]) not in drop and (p[1], p[2][1]) not in drop]
+    b.batched_unary_kws = [[]]
+    return b
 
 
 FORWARD_CASES = {
@@ -28,13 +45,23 @@ FORWARD_CASES = {
     "tiny_empty_kws": ("tiny", 13, dict(seed=9, n_videos=1, frames=2, objects=3), dict()),
     "tiny_no_pairs": ("tiny", 13, dict(seed=10, n_videos=1, frames=2, objects=2), dict()),
     "b32_infer": ("vit-b-32", 21, dict(seed=31, n_videos=1, frames=2, objects=3, H=240, W=320), dict(output_embeddings=True)),
+    # training-mode pair selection (batched_binary_predicates given) at ViT-B/32 width: the selected pair set depends on
+    # the floating-point ranking of the per-object category means (llava_clip_model_v3.py:347-392).  With random weights
+    # those means lie within ~1e-3 of each other for most seeded clips; this seed is the one of 120 scanned whose
+    # third and fourth candidates of every name the predicates use are furthest apart (8.9e-3, recorded by the
+    # generator as topk_ranking_margin), so bf16 rounding cannot change the selected set
+    "b32_train": ("vit-b-32", 22, dict(seed=134, n_videos=2, frames=3, objects=5, H=240, W=320, train=True, max_box=220),
+                  dict(output_embeddings=True)),
+    # BASELINE.json configs[0]: one demo-shaped clip, 8 frames x <= 5 masks at 1280 x 720, the evaluation driver's call
+    "c1_demo_clip": ("vit-b-32", 23, dict(kind="demo", seed=35), dict()),
 }
 
 
 
 def build_case_batch(name: str):
     _, _, bk, _ = FORWARD_CASES[name]
-    b = tiny_batch(**bk)
+    bk = dict(bk)
+    b = demo_clip_batch(**bk) if bk.pop("kind", None) == "demo" else tiny_batch(**bk)
     if name == "tiny_empty_kws":
         b.batched_unary_kws = [[]]
     if name == "tiny_no_pairs":

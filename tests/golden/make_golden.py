@@ -22,7 +22,7 @@ pooled tensor as transformers 4.46.2 did, HF's PIL image processor with CLIP
 defaults, and the repo's deterministic HashTokenizer.  `forward()` itself runs
 unmodified.
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [forward case name ...]
 """
 from __future__ import annotations
 
@@ -222,10 +222,30 @@ def gen_function_goldens(mu):
     print("functions.npz", sum(a.nbytes for a in arrays.values()) // 1024, "KiB raw")
 
 
-def gen_forward_goldens(ref_model_mod):
+def ranking_margin(cate, predicates, topk=3):
+    """Smallest gap between the last selected and the first rejected per-object category mean over the
+    (video, name) the predicates use: how far the training-mode candidate sets are from flipping under rounding."""
+    worst = float("inf")
+    for vid, d in cate.items():
+        used = {n for (_, a, b) in predicates[vid] for n in (a, b)}
+        by_name = {}
+        for (oid, nm), p in d.items():
+            if nm in used:
+                by_name.setdefault(nm, []).append(float(p))
+        for ps in by_name.values():
+            ps.sort(reverse=True)
+            if len(ps) > topk:
+                worst = min(worst, ps[topk - 1] - ps[topk])
+    return worst
+
+
+def gen_forward_goldens(ref_model_mod, only=None):
     from laser_amd.config import config_by_name
-    index = {}
+    index_path = os.path.join(HERE, "forward_index.json")
+    index = json.load(open(index_path)) if only and os.path.exists(index_path) else {}
     for name, (cfg_name, wseed, bk, fk) in FORWARD_CASES.items():
+        if only and name not in only:
+            continue
         cfg = config_by_name(cfg_name)
         torch.manual_seed(0)
         pm = build_reference_model(ref_model_mod, cfg, wseed, logit_scale=float(np.log(100.0)))
@@ -234,13 +254,18 @@ def gen_forward_goldens(ref_model_mod):
             out = pm(**b.forward_kwargs(), **fk)
         rec, arrays = pack_outputs(out)
         rec.update({"cfg": cfg_name, "weight_seed": wseed, "batch": bk, "forward": fk, "logit_scale": float(np.log(100.0))})
+        if b.batched_binary_predicates[0] is not None:
+            rec["topk_ranking_margin"] = ranking_margin(out[0], b.batched_binary_predicates)
+            print(name, "top-3 ranking margin", rec["topk_ranking_margin"])
         np.savez_compressed(os.path.join(HERE, f"forward_{name}.npz"), **arrays)
         index[name] = rec
         print(name, {k: v.shape for k, v in arrays.items() if hasattr(v, "shape") and v.ndim}, float(out[3]))
-    json.dump(index, open(os.path.join(HERE, "forward_index.json"), "w"))
+    json.dump(index, open(index_path, "w"))
 
 
 if __name__ == "__main__":
+    only = set(sys.argv[1:])          # optional: names of the forward cases to (re)generate; default everything
     mu, mm = load_reference()
-    gen_function_goldens(mu)
-    gen_forward_goldens(mm)
+    if not only:
+        gen_function_goldens(mu)
+    gen_forward_goldens(mm, only)

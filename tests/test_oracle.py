@@ -108,8 +108,9 @@ def test_oracle_forward_matches_reference(name):
         assert want_pairs == list(emb["binary_object_pairs"][0])
 
 
-def test_oracle_forward_b32_matches_reference():
-    name = "b32_infer"
+@pytest.mark.parametrize("name", [n for n in FORWARD_CASES if not n.startswith("tiny")])
+def test_oracle_forward_b32_matches_reference(name):
+    """ViT-B/32 width: inference, training-mode pair selection, and the demo-clip shape of the evaluation driver."""
     rec, cate, unary, binary, dummy, z = load_forward_case(name)
     model, fk = _oracle_for(name)
     torch.set_num_threads(8)
@@ -117,6 +118,13 @@ def test_oracle_forward_b32_matches_reference():
     for v in cate:
         compare_prob_dicts(out[0][v], cate[v], 5e-5)
         compare_prob_dicts(out[1][v], unary[v], 5e-5)
+    assert len(out[2]) == len(binary)
     for g, w in zip(out[2], binary):
         compare_prob_dicts(g, w, 5e-5)
-    np.testing.assert_allclose(out[4]["binary_obj_pair_features"][0].numpy(), z["binary_obj_pair_features_0"], atol=5e-5, rtol=1e-4)
+    assert abs(float(out[3]) - dummy) <= 1e-3
+    if fk.get("output_embeddings"):
+        for v in range(len(binary)):
+            np.testing.assert_allclose(out[4]["binary_obj_pair_features"][v].numpy(), z[f"binary_obj_pair_features_{v}"],
+                                       atol=5e-5, rtol=1e-4)
+            want_pairs = [(p[0], p[1], tuple(p[2])) for p in rec["binary_object_pairs"][str(v)]]
+            assert want_pairs == list(out[4]["binary_object_pairs"][v])
