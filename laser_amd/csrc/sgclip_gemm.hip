@@ -959,7 +959,9 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
         const char *e = getenv("SGCLIP_PIPE64_MIN_TILES");
         min_tiles = e ? atoi(e) : 256;
     }
-    if (variant >= 7 && big_tiles >= min_tiles && g.M > 128 && g.K % 64 == 0 && g.K >= 128 && g.N >= 256) {
+    // the last K slice of a split launch is the shortest (split_k_setup): the 64-deep pipeline needs two stages of it
+    const int k_shortest = g.k_total - (splits - 1) * g.K;
+    if (variant >= 7 && big_tiles >= min_tiles && g.M > 128 && g.K % 64 == 0 && k_shortest >= 128 && g.N >= 256) {
         g.tiles_m = ceil_div(g.M, 256);
         g.tiles_n = ceil_div(g.N, 256);
         auto go = [&](auto kernel) {
@@ -1052,6 +1054,9 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
         if (dbg < 0) {
             const char *e = getenv("SGCLIP_GEMM_DEBUG");
             dbg = e ? atoi(e) : 0;
+            if (dbg)
+                fprintf(stderr, "sgclip: SGCLIP_GEMM_DEBUG=%d is a profiling mode: sgclip_gemm_bf16 skips part of its work and "
+                                "its RESULTS ARE WRONG\n", dbg);
         }
         g.debug_mode = dbg;
     }

@@ -77,8 +77,10 @@ def pack_masks(masks: Sequence[np.ndarray]) -> PackedMasks:
 class UnpackedMasks:
     """Result of `unpack_to_device`: byte-per-pixel masks in HBM + per-mask boxes."""
 
-    def __init__(self, masks: torch.Tensor, offsets: List[int], ndims: List[int], boxes: torch.Tensor):
+    def __init__(self, masks: torch.Tensor, offsets: List[int], ndims: List[int], boxes: torch.Tensor,
+                 shapes: Optional[List[tuple]] = None):
         self.masks, self.offsets, self.ndims, self._boxes_dev = masks, offsets, ndims, boxes
+        self.shapes = list(shapes) if shapes is not None else None    # (H, W) per mask
         self._boxes: Optional[np.ndarray] = None
 
     @property
@@ -113,6 +115,6 @@ def unpack_to_device(packed: PackedMasks, device) -> UnpackedMasks:
         pk = torch.from_numpy(packed.data).to(device, non_blocking=True)
         table_dev = torch.empty(n * C.sizeof(_lib.MaskEntry), dtype=torch.uint8, device=device)
         _lib.check(lib.sgclip_mask_unpack(pk.data_ptr(), pk.numel(), C.addressof(table), table_dev.data_ptr(), n,
-                                          out.data_ptr(), off, boxes.data_ptr(), ops._stream()))
+                                          out.data_ptr(), off, boxes.data_ptr(), ops._stream(out)))
         out._sgclip_keepalive = (pk, table_dev, table)
-    return UnpackedMasks(out, offsets, list(packed.ndims), boxes)
+    return UnpackedMasks(out, offsets, list(packed.ndims), boxes, [tuple(s) for s in packed.shapes])

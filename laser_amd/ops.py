@@ -15,7 +15,14 @@ CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
-def _stream() -> int:
+def _stream(t: Optional[torch.Tensor] = None) -> int:
+    """The HIP stream a call is queued on: torch's current stream of the current device.  `t` is a tensor the
+    kernel will touch: its device must be the current one (HIP launches on the current device; a pointer of
+    another GPU would fault there), so callers with tensors elsewhere run under `torch.cuda.device(...)`,
+    as PredicateModel does for its own device."""
+    if t is not None and t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"tensor on {t.device} but the current HIP device is cuda:{torch.cuda.current_device()}: "
+                           f"run this call under torch.cuda.device({t.device.index})")
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -83,7 +90,7 @@ def crop_preprocess(frames: torch.Tensor, masks: Optional[torch.Tensor], entries
         frames.data_ptr(), frames.numel() - PAD, _ptr(masks), (masks.numel() - PAD) if masks is not None else 0,
         _host_table_ptr(entries) if n else None, entries_dev.data_ptr(), 1 if entries_dev_ready else 0, n,
         luts.ctypes.data, nlut.ctypes.data, lut_dev.data_ptr(), S, layout, patch, kpad, out_dtype, out.data_ptr(),
-        _stream())
+        _stream(frames))
     _lib.check(rc)
     # lut_dev / entries_dev are consumed asynchronously: keep them alive until the stream has run
     out._sgclip_keepalive = (lut_dev, entries_dev)
@@ -191,7 +198,7 @@ class Tower:
         if out is None:
             out = torch.empty((n_images, self.cfg.proj), dtype=torch.float32, device=self.device)
         _lib.check(lib.sgclip_vit_encode(C.byref(self.desc), self.wb.data_ptr(), self.wf.data_ptr(), patches.data_ptr(),
-                                         n_images, ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()))
+                                         n_images, ws.data_ptr(), ws.numel(), out.data_ptr(), _stream(patches)))
         return out
 
     def pooled_length(self, input_ids: torch.Tensor) -> int:
@@ -223,7 +230,7 @@ class Tower:
         ws = self._workspace(max(need, 256))
         out = torch.empty((K, self.cfg.proj), dtype=torch.float32, device=self.device)
         _lib.check(lib.sgclip_text_encode(C.byref(self.desc), self.wb.data_ptr(), self.wf.data_ptr(), ids.data_ptr(),
-                                          _ptr(am), K, T, ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()))
+                                          _ptr(am), K, T, ws.data_ptr(), ws.numel(), out.data_ptr(), _stream(ids)))
         out._sgclip_keepalive = (ids, am)
         return out
 
@@ -241,7 +248,7 @@ def similarity(text: torch.Tensor, img: torch.Tensor, exp_logit_scale: float, mo
         out = torch.empty((K, N), dtype=torch.float32, device=text.device)
     ws = torch.empty(max(lib.sgclip_similarity_workspace_bytes(K, N), 256), dtype=torch.uint8, device=text.device)
     _lib.check(lib.sgclip_similarity(text.data_ptr(), img.data_ptr(), K, N, E, float(exp_logit_scale), mode,
-                                     out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+                                     out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(img)))
     out._sgclip_keepalive = (ws, text, img)
     return out
 
@@ -251,7 +258,7 @@ def segment_mean(probs: torch.Tensor, seg_ids: torch.Tensor, G: int) -> torch.Te
     K, N = probs.shape
     out = torch.empty((K, G), dtype=torch.float32, device=probs.device)
     seg = seg_ids.to(probs.device, torch.int32).contiguous()
-    _lib.check(lib.sgclip_segment_mean(probs.data_ptr(), seg.data_ptr(), K, N, G, out.data_ptr(), _stream()))
+    _lib.check(lib.sgclip_segment_mean(probs.data_ptr(), seg.data_ptr(), K, N, G, out.data_ptr(), _stream(probs)))
     out._sgclip_keepalive = (seg,)
     return out
 

@@ -37,9 +37,20 @@ assert CROP_DTYPE.itemsize == 56
 def _no_grad_unless_training(fn):
     @functools.wraps(fn)
     def wrapper(self, *args, **kwargs):
-        if self._grad_mode():
-            return fn(self, *args, **kwargs)
-        with torch.no_grad():
+        # every kernel of the call is launched on, and every stream / event belongs to, the model's own GPU,
+        # whatever the caller's current device is (the reference's `.to(device)` modules allow the same)
+        with torch.cuda.device(self.device):
+            if self._grad_mode():
+                return fn(self, *args, **kwargs)
+            with torch.no_grad():
+                return fn(self, *args, **kwargs)
+    return wrapper
+
+
+def _on_own_device(fn):
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        with torch.cuda.device(self.device):
             return fn(self, *args, **kwargs)
     return wrapper
 
@@ -93,9 +104,10 @@ class DeviceInputs:
     """Frames and masks of one forward() call resident in HBM."""
 
     def __init__(self, frames: torch.Tensor, frame_off: List[int], frame_hw: List[tuple], masks: Optional[torch.Tensor],
-                 mask_off: List[int], mask_ndim: List[int], unpacked=None):
+                 mask_off: List[int], mask_ndim: List[int], unpacked=None, mask_hw: Optional[List[tuple]] = None):
         self.frames, self.frame_off, self.frame_hw = frames, frame_off, frame_hw
         self.masks, self.mask_off, self.mask_ndim = masks, mask_off, mask_ndim
+        self.mask_hw = mask_hw    # (H, W) per mask; forward() checks each against its frame
         self.unpacked = unpacked  # laser_amd.masks.UnpackedMasks when the masks arrived bit-packed
 
     def bbox_dicts(self):
@@ -160,6 +172,7 @@ class PredicateModel(nn.Module):
         self.requires_grad_(on)
         return self
 
+    @_on_own_device
     def flatten_parameters(self) -> "training.FlatParameters":
         """Move every parameter (and its gradient) into one fp32 buffer each, see `training.FlatParameters`:
         weight gradients are accumulated in place, `training.Adam(flat)` is one launch, and
@@ -210,6 +223,7 @@ class PredicateModel(nn.Module):
             self.invalidate_packed_weights()
             self._packed_versions = versions
 
+    @_on_own_device
     def _packed(self):
         if self._towers is None:
             towers = {}
@@ -221,6 +235,7 @@ class PredicateModel(nn.Module):
         return self._towers
 
     # -- inputs ----------------------------------------------------------------
+    @_on_own_device
     def stage_inputs(self, batched_videos, batched_masks) -> DeviceInputs:
         """Upload frames (u8[H,W,3]) and masks (anything `.astype(bool)` accepts, [H,W,1]
         or [H,W]; or a `laser_amd.masks.PackedMasks`, uploaded as bits and expanded on the
@@ -237,8 +252,8 @@ class PredicateModel(nn.Module):
         if isinstance(batched_masks, PackedMasks):
             un = unpack_to_device(batched_masks, self.device)
             return DeviceInputs(frames, frame_off, frame_hw, un.masks if len(batched_masks) else None, un.offsets,
-                                un.ndims, unpacked=un)
-        mask_off, mask_ndim, mchunks, off = [], [], [], 0
+                                un.ndims, unpacked=un, mask_hw=un.shapes)
+        mask_off, mask_ndim, mask_hw, mchunks, off = [], [], [], [], 0
         for m in batched_masks:
             m = np.asarray(m)
             mask_ndim.append(m.ndim)
@@ -246,6 +261,9 @@ class PredicateModel(nn.Module):
                 if m.shape[2] != 1:
                     raise ValueError(f"masks must be [H,W,1] or [H,W], got {m.shape}")
                 m = m[:, :, 0]
+            elif m.ndim != 2:
+                raise ValueError(f"masks must be [H,W,1] or [H,W], got {m.shape}")
+            mask_hw.append((m.shape[0], m.shape[1]))
             m = np.ascontiguousarray(m.astype(bool)).view(np.uint8)
             mask_off.append(off); mchunks.append(m.reshape(-1))
             off += m.size
@@ -253,7 +271,7 @@ class PredicateModel(nn.Module):
         if mchunks:
             mchunks.append(np.zeros(ops.PAD, dtype=np.uint8))
             masks = torch.from_numpy(np.concatenate(mchunks)).to(self.device, non_blocking=True)
-        return DeviceInputs(frames, frame_off, frame_hw, masks, mask_off, mask_ndim)
+        return DeviceInputs(frames, frame_off, frame_hw, masks, mask_off, mask_ndim, mask_hw=mask_hw)
 
     def _text_features(self, prefix: str, kws: Sequence[str]) -> torch.Tensor:
         if self._grad_mode():
@@ -349,6 +367,10 @@ class PredicateModel(nn.Module):
                 break                                    # zip() in the reference stops at the shortest list
             fidx = splits[vid] + fid
             H, W = di.frame_hw[fidx]
+            if di.mask_hw is not None and tuple(di.mask_hw[pos]) != (H, W):
+                # the reference's np.where / addWeighted raise on such a pair of arrays (model_utils.py:48-54)
+                raise ValueError(f"mask {pos} of object {(vid, fid, oid)} is {tuple(di.mask_hw[pos])}, its frame is "
+                                 f"{(H, W)}: {batched_video_ids}")
             x1, y1, x2, y2 = resolve_union_box([bbox], batched_video_ids)
             obj_box[pos] = (x1, y1, x2, y2)
             xa, ya, xb, yb = slice_box(x1, y1, x2, y2, W, H, batched_video_ids)

@@ -306,3 +306,18 @@ def test_forward_input_variants_vs_oracle(seed):
         worst = max(worst, compare_prob_dicts(g, {k: float(x) for k, x in w.items()}, PROB_TOL))
     assert abs(float(got[3]) - float(want[3])) <= PROB_TOL
     print(f"variants seed {seed}: max |p - oracle| = {worst:.3e}")
+
+
+def test_mask_of_another_shape_than_its_frame_is_refused():
+    """The reference's np.where / cv2.addWeighted raise when a mask and its frame differ in shape
+    (model_utils.py:48-54); here the crop table would otherwise address the mask with the frame's geometry."""
+    from laser_amd.masks import pack_masks
+    model = _model("tiny", 11)
+    kw = build_case_batch("tiny_infer").forward_kwargs()
+    kw["batched_masks"] = list(kw["batched_masks"])
+    kw["batched_masks"][2] = np.ascontiguousarray(np.asarray(kw["batched_masks"][2])[:-3])      # 3 rows short
+    with pytest.raises(ValueError, match="its frame is"):
+        model(**kw)
+    kw["batched_masks"][2] = np.ascontiguousarray(np.asarray(kw["batched_masks"][2]).transpose(1, 0, 2))
+    with pytest.raises(ValueError, match="its frame is"):
+        model(**dict(kw, batched_masks=pack_masks(kw["batched_masks"])))
