@@ -166,6 +166,17 @@ size_t sgclip_similarity_workspace_bytes(int K, int N);
 int sgclip_similarity(const float *text_dev, const float *img_dev, int K, int N, int E, float exp_logit_scale,
                       int mode, float *out_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* The same computation for callers that cannot allocate device memory or pass a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * The inverse row norms that sgclip_similarity keeps in its workspace live in a static device array of
+ * sgclip_similarity_static_max() floats (65 536 = 256 KiB, held on every GPU the library runs on until the
+ * process ends): K + N beyond that returns SGCLIP_ENOSPC.  The call allocates and frees nothing.  All calls on
+ * one GPU share the array: two calls that overlap on one GPU (different streams or threads) race; calls on
+ * one stream are ordered and safe.  The current HIP device must be the one the pointers live on. */
+int sgclip_similarity_static_max(void);
+int sgclip_similarity_static(const float *text_dev, const float *img_dev, int K, int N, int E, float exp_logit_scale,
+                             int mode, float *out_dev, void *stream);
+
 /* ------------------------------------------------------------------------
  * (4) per-object mean of category probabilities over frames.
  *

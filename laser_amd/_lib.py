@@ -64,6 +64,9 @@ SIGNATURES = {
     "sgclip_similarity_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "sgclip_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sgclip_similarity_static_max": (C.c_int, []),
+    "sgclip_similarity_static": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p,
+                                           C.c_void_p]),
     "sgclip_segment_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sgclip_topk_columns": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),

@@ -4,6 +4,8 @@
 // wavefront reductions, and the per-object mean of category probabilities.
 #include "common.h"
 
+#include <mutex>
+
 namespace sgclip {
 
 // ---------------------------------------------------------------------------
@@ -220,6 +222,59 @@ extern "C" int sgclip_similarity(const float *text_dev, const float *img_dev, in
         return SGCLIP_EINVAL;
     }
     return launch_check("sgclip_similarity");
+}
+
+// ---------------------------------------------------------------------------
+// sgclip_similarity without a caller workspace and without any allocation: the inverse row norms
+// (the partial results sgclip_similarity keeps in its workspace) live in a file-scope device array.
+// The array's name is a host-side handle, not a device address: its address on each GPU comes from
+// hipGetSymbolAddress, asked once per device with that device current, and only that pointer is
+// handed to kernels.
+// ---------------------------------------------------------------------------
+namespace sgclip {
+constexpr int SIM_STATIC_MAX = 65536;   // K + N floats: 256 KiB on every GPU the library runs on
+static __device__ __align__(256) float scratch[SIM_STATIC_MAX];
+constexpr int MAX_DEVICES = 64;
+static float *g_scratch_ptr[MAX_DEVICES];   // per device: each GPU holds its own copy of the array
+static std::mutex g_scratch_mu;
+
+// device address of `scratch` on the current device (nullptr + error text on failure)
+static float *static_scratch() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= MAX_DEVICES) {
+        set_error("sgclip_similarity_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            set_error("sgclip_similarity_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = (float *)p;
+    }
+    return g_scratch_ptr[dev];
+}
+}  // namespace sgclip
+
+extern "C" int sgclip_similarity_static_max(void) { return SIM_STATIC_MAX; }
+
+extern "C" int sgclip_similarity_static(const float *text_dev, const float *img_dev, int K, int N, int E,
+                                        float exp_logit_scale, int mode, float *out_dev, void *stream_) {
+    if (K == 0 || N == 0) return SGCLIP_OK;
+    if (K < 0 || N < 0 || (long long)K + N > SIM_STATIC_MAX) {
+        set_error("sgclip_similarity_static: K + N = %lld exceeds the static scratch of %d floats; use "
+                  "sgclip_similarity with a workspace", (long long)K + N, SIM_STATIC_MAX);
+        return SGCLIP_ENOSPC;
+    }
+    float *ws = static_scratch();
+    if (!ws) return SGCLIP_ELAUNCH;
+    // every one of the K + N entries read is written first by this call: nothing to clear
+    return sgclip_similarity(text_dev, img_dev, K, N, E, exp_logit_scale, mode, out_dev, ws,
+                             sgclip_similarity_workspace_bytes(K, N), stream_);
 }
 
 extern "C" int sgclip_linear_f32(const float *x_dev, const float *w_dev, int rows, int out_features, int in_features,
