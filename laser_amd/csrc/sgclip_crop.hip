@@ -17,6 +17,9 @@
 // stored 16 bytes per lane).  HBM traffic is the crop's own box of frame + mask
 // bytes (re-read only where neighbouring bands overlap by the filter support)
 // plus the output.
+// A crop whose source span is too wide for that staging to fit the LDS (frames beyond ~1 700 px on the
+// short side, e.g. a whole 4K frame) runs the same passes over SEGMENTS of output columns: passes A-C
+// once per segment and chunk on the segment's own source span, pass D after the last segment.
 //
 // Replaces laser/models/model_utils.py:29-56,87-140 and the HF CLIPImageProcessor
 // call at laser/models/llava_clip_model_v3.py:244,443 (PIL Resample.c semantics).
@@ -166,7 +169,11 @@ struct CropArgs {
     int bands_per_wg;      // divides nbands; a workgroup walks this many consecutive bands
     int ksx_cap, ksy_cap, wn_cap;
     int need_lo, need_hi;  // this launch handles the crops whose own LDS need is in (need_lo, need_hi]
+    int nseg;              // column segments (segmented launch only; 1 otherwise)
 };
+
+// output columns of segment s: [seg_begin(s), seg_begin(s + 1)); column c lies in segment c * nseg / S
+__host__ __device__ inline int seg_begin(int s, int S, int nseg) { return (s * S + nseg - 1) / nseg; }
 
 // LDS bytes one crop needs when staged with exactly its own tap counts and source span
 __host__ __device__ inline int crop_need(int w, int h, int S, int vrows) {
@@ -190,7 +197,7 @@ __device__ __forceinline__ int fresh(int v) {
     return v;
 }
 
-template <int CPT>
+template <int CPT, bool SEG>
 __global__ __launch_bounds__(NT, 4) void crop_kernel(CropArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -249,15 +256,30 @@ __global__ __launch_bounds__(NT, 4) void crop_kernel(CropArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int cx0 = __builtin_amdgcn_readfirstlane(xmin[0]);
-    const int wn = __builtin_amdgcn_readfirstlane(xmin[S - 1] + xcnt[S - 1]) - cx0;
-    if (wn > a.wn_cap) return;  // host sizing guarantees this never triggers
+    const int nseg = SEG ? a.nseg : 1;
+    // source span staged at a time: the whole visible span, or one segment's (set per segment below)
+    int cx0 = __builtin_amdgcn_readfirstlane(xmin[0]);
+    int wn = __builtin_amdgcn_readfirstlane(xmin[S - 1] + xcnt[S - 1]) - cx0;
+    auto seg_span = [&](int sg) {
+        const int c0 = seg_begin(sg, S, nseg), c1 = seg_begin(sg + 1, S, nseg) - 1;
+        cx0 = __builtin_amdgcn_readfirstlane(xmin[c0]);
+        wn = __builtin_amdgcn_readfirstlane(xmin[c1] + xcnt[c1]) - cx0;
+    };
+    if (SEG) {
+        for (int sg = 0; sg < nseg; sg++) {
+            seg_span(sg);
+            if (wn > a.wn_cap) return;  // host sizing guarantees this never triggers
+        }
+        seg_span(0);
+    } else if (wn > a.wn_cap) {
+        return;  // host sizing guarantees this never triggers
+    }
 
-    int hx[CPT], hn[CPT];  // this thread's columns: first source pixel (relative) and tap count
+    int hx[CPT], hn[CPT];  // this thread's columns: first source pixel (relative to its segment's span) and tap count
 #pragma unroll
     for (int cc = 0; cc < CPT; cc++) {
         const int col = min(gcol + cc * COLS, S - 1);
-        hx[cc] = xmin[col] - cx0;
+        hx[cc] = xmin[col] - (SEG ? xmin[seg_begin(col * nseg / S, S, nseg)] : cx0);
         hn[cc] = xcnt[col];
     }
 
@@ -321,6 +343,7 @@ __global__ __launch_bounds__(NT, 4) void crop_kernel(CropArgs a) {
 
         for (int cy = ry0; cy < ry1; cy += CH) {
             const int nrows = min(CH, ry1 - cy);
+          for (int sg = 0; sg < nseg; sg++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             // ---- B: blend -> packed pixels; thread = source column, all rows of the chunk, so
@@ -389,18 +412,25 @@ __global__ __launch_bounds__(NT, 4) void crop_kernel(CropArgs a) {
                     blend(std::integral_constant<int, 1>{});
             }
             __syncthreads();
-            // the raw bytes are consumed: refill them underneath C and D
-            if (cy + CH < ry1)
-                issue_chunk(cy + CH, ry1);
-            else if (bl + 1 < bpw)
-                issue_chunk(nry0, nry1);
+            // the raw bytes are consumed: refill them underneath C and D (next segment of this chunk, else
+            // the first segment of the next chunk / band)
+            if (SEG && sg + 1 < nseg) {
+                seg_span(sg + 1);
+                issue_chunk(cy, ry1);
+            } else {
+                if (SEG) seg_span(0);
+                if (cy + CH < ry1)
+                    issue_chunk(cy + CH, ry1);
+                else if (bl + 1 < bpw)
+                    issue_chunk(nry0, nry1);
+            }
             // ---- C: horizontal pass, thread = output column x CR chunk rows
             if (grp * CR < nrows) {
                 const int ccol = fresh(gcol);
 #pragma unroll
                 for (int cc = 0; cc < CPT; cc++) {
                     const int col = ccol + cc * COLS;
-                    if (col < S) {
+                    if (col < S && (!SEG || col * nseg / S == sg)) {
                         const int xm = hx[cc], n = hn[cc];
                         int acc[CR][3];
 #pragma unroll
@@ -435,6 +465,7 @@ __global__ __launch_bounds__(NT, 4) void crop_kernel(CropArgs a) {
                     }
                 }
             }
+          }
             __syncthreads();
             // ---- D: vertical pass, thread = output column x DR output rows; accumulate this chunk's rows
             const int dcol = fresh(gcol);
@@ -569,13 +600,14 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
         const int v = atoi(e);
         if (v > 0 && nbands % v == 0) bpw = v;
     }
-    // occupancy classes by LDS need: 4 / 3 / 2 / 1 workgroups per CU
+    // occupancy classes by LDS need: 4 / 3 / 2 / 1 workgroups per CU; class 4 = crops whose whole visible source span
+    // does not fit even with one band per workgroup: they run over column segments
     static const int class_hi[4] = {40 * 1024, 53 * 1024, 80 * 1024, LDS_LIMIT};
-    int ksx[4], ksy[4], wnc[4], members[4];
+    int ksx[5], ksy[5], wnc[5], members[5];
     double algo_bytes = 0;  // per crop: 3hw frame + m*hw mask + out
     for (;;) {
         bool too_big = false;
-        for (int k = 0; k < 4; k++) ksx[k] = ksy[k] = wnc[k] = 1, members[k] = 0;
+        for (int k = 0; k < 5; k++) ksx[k] = ksy[k] = wnc[k] = 1, members[k] = 0;
         algo_bytes = 0;
         for (int i = 0; i < n_crops; i++) {
             const sgclip_crop_t &c = crops[i];
@@ -608,17 +640,16 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
             axis_bounds(w, new_w, left, x0, n0);
             axis_bounds(w, new_w, left + S - 1, x1, n1);
             const int need = crop_need(w, h, S, bpw * BR);
+            int k = 0;
             if (need > LDS_LIMIT) {
                 if (bpw > 1) {
                     too_big = true;
                     break;
                 }
-                set_error("sgclip_crop_preprocess: crop %d needs %d bytes of LDS staging (limit %d): source span %d px", i,
-                          need, LDS_LIMIT, x1 + n1 - x0);
-                return SGCLIP_EINVAL;
+                k = 4;
+            } else {
+                while (need > class_hi[k]) k++;
             }
-            int k = 0;
-            while (need > class_hi[k]) k++;
             ksx[k] = std::max(ksx[k], axis_ksize(w, new_w));
             ksy[k] = std::max(ksy[k], axis_ksize(h, new_h));
             wnc[k] = std::max(wnc[k], x1 + n1 - x0);
@@ -635,6 +666,33 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
             return SGCLIP_EINVAL;
         }
         bpw = 1;  // per-band coefficient tables are the smallest layout
+    }
+    // segmented class: the fewest column segments whose widest source span fits the LDS
+    int nseg = 1;
+    if (members[4]) {
+        for (nseg = 2; nseg <= S; nseg++) {
+            int span = 1;
+            for (int i = 0; i < n_crops; i++) {
+                const sgclip_crop_t &c = crops[i];
+                const int w = c.x2 - c.x1, h = c.y2 - c.y1;
+                if (crop_need(w, h, S, BR) <= LDS_LIMIT) continue;
+                int new_w, new_h, top, left;
+                crop_geom(w, h, S, new_w, new_h, top, left);
+                for (int sg = 0; sg < nseg; sg++) {
+                    int x0, n0, x1, n1;
+                    axis_bounds(w, new_w, left + seg_begin(sg, S, nseg), x0, n0);
+                    axis_bounds(w, new_w, left + seg_begin(sg + 1, S, nseg) - 1, x1, n1);
+                    span = std::max(span, x1 + n1 - x0);
+                }
+            }
+            wnc[4] = span;
+            if (crop_lds(S, ksx[4], ksy[4], span, BR).total <= LDS_LIMIT) break;
+        }
+        if (nseg > S) {
+            set_error("sgclip_crop_preprocess: a crop's resampling tables alone (%d x %d taps) exceed the %d bytes of LDS",
+                      ksx[4], ksy[4], LDS_LIMIT);
+            return SGCLIP_EINVAL;
+        }
     }
     uint8_t *lut8_dev = (uint8_t *)lut_dev;
     float *norm_dev = (float *)(lut8_dev + 768);
@@ -662,20 +720,24 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
     a.out_dtype = out_dtype;
     const dim3 grid((unsigned)n_crops * (nbands / bpw)), block(NT);
     KernelTimer timer(TK_CROP, algo_bytes, stream);
-    for (int k = 0; k < 4; k++) {
+    a.nseg = 1;
+    for (int k = 0; k < 5; k++) {
         if (!members[k]) continue;
         a.ksx_cap = ksx[k];
         a.ksy_cap = ksy[k];
         a.wn_cap = wnc[k];
         a.need_lo = k ? class_hi[k - 1] : 0;
-        a.need_hi = class_hi[k];
+        a.need_hi = k < 4 ? class_hi[k] : INT32_MAX;
         const int lds_bytes = crop_lds(S, ksx[k], ksy[k], wnc[k], bpw * BR).total;
-        if (S <= COLS) {
-            (void)hipFuncSetAttribute((const void *)crop_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-            hipLaunchKernelGGL(crop_kernel<1>, grid, block, lds_bytes, stream, a);
+        auto go = [&](auto kernel) {
+            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, a);
+        };
+        if (k == 4) {
+            a.nseg = nseg;
+            if (S <= COLS) go(crop_kernel<1, true>); else go(crop_kernel<2, true>);
         } else {
-            (void)hipFuncSetAttribute((const void *)crop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-            hipLaunchKernelGGL(crop_kernel<2>, grid, block, lds_bytes, stream, a);
+            if (S <= COLS) go(crop_kernel<1, false>); else go(crop_kernel<2, false>);
         }
     }
     return launch_check("sgclip_crop_preprocess");

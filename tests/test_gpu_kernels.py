@@ -315,6 +315,43 @@ def test_crop_random_boxes_vs_oracle(dev, bands, monkeypatch):
             assert np.array_equal(out[i], want), f"S={S} crop {i} box {boxes[i]}: {(out[i] != want).sum()} values differ"
 
 
+def test_crop_of_4k_frames_beyond_the_lds_staging(dev):
+    """Source spans too wide for one LDS staging (the reference slices any box of any frame, model_utils.py:117, and
+    uses the whole first frame as the stand-in pair, llava_clip_model_v3.py:416-420): a whole 3840 x 2160 frame, a
+    large pair union box and an object box on it, mixed in one call with small crops; S = 224 and 336, both layouts'
+    bits against the oracle."""
+    from oracle import crop_ref, resample_ref
+    rng = np.random.default_rng(21)
+    H, W = 2160, 3840
+    frame = (rng.integers(0, 256, size=(H, W, 3)) // 2 + np.linspace(0, 127, W)[None, :, None]).astype(np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    masks = np.stack([((xx - 1500) / 1400.0) ** 2 + ((yy - 1000) / 900.0) ** 2 <= 1.0,
+                      ((xx - 2600) / 1100.0) ** 2 + ((yy - 1300) / 800.0) ** 2 <= 1.0])
+    frames_t = torch.from_numpy(ops.pad_bytes(frame)).to(dev)
+    masks_t = torch.from_numpy(ops.pad_bytes(masks.astype(np.uint8))).to(dev)
+    boxes = [(0, 0, W, H, _lib.CROP_PLAIN), (100, 100, 3700, 2100, _lib.CROP_PAIR), (100, 100, 2900, 1900, _lib.CROP_OBJECT),
+             (17, 33, 3840, 2160, _lib.CROP_PAIR), (1000, 1000, 1200, 1300, _lib.CROP_PAIR), (5, 5, 3001, 120, _lib.CROP_OBJECT)]
+    rows = [(0, 0, H * W, W, H, x1, y1, x2, y2, mode) for (x1, y1, x2, y2, mode) in boxes]
+    ent = _entries(rows)
+    for S in (224, 336):
+        out = ops.crop_preprocess(frames_t, masks_t, ent, S).cpu().numpy()
+        for i, (x1, y1, x2, y2, mode) in enumerate(boxes):
+            if mode == _lib.CROP_OBJECT:
+                full = crop_ref.extract_single_object(frame, masks[0][..., None], 0.8)
+            elif mode == _lib.CROP_PAIR:
+                full = crop_ref.extract_object_subject(frame, masks[0][..., None], masks[1][..., None], 0.5, 0.8)
+            else:
+                full = frame
+            want = resample_ref.preprocess(full[y1:y2, x1:x2], S)
+            assert np.array_equal(out[i], want), f"S={S} crop {i} box {boxes[i]}: {(out[i] != want).sum()} values differ"
+    p = 32
+    outp = ops.crop_preprocess(frames_t, masks_t, ent, 224, layout=_lib.LAYOUT_PATCHES, patch=p, out_dtype=_lib.DTYPE_BF16)
+    G = 224 // p
+    chw = ops.crop_preprocess(frames_t, masks_t, ent, 224).to(torch.bfloat16).float().cpu()
+    want = chw.view(len(rows), 3, G, p, G, p).permute(0, 2, 4, 1, 3, 5).reshape(len(rows) * G * G, 3 * p * p)
+    assert torch.equal(outp.float().cpu(), want)
+
+
 def test_crop_errors(dev):
     frames_t = torch.zeros(100 * 100 * 3 + ops.PAD, dtype=torch.uint8, device=dev)
     with pytest.raises(AssertionError, match="image bbox issue"):
