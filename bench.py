@@ -62,6 +62,8 @@ def parse():
                     help="skip timing PredicateModel.forward() from host numpy inputs (PCIe + host index build included)")
     ap.add_argument("--no-c4", action="store_true",
                     help="skip the ViT-L/14-336 sub-result (1 frame x 64 objects x 4 032 pairs)")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the train-step sub-result (two clips of the headline shape, forward + backward + Adam)")
     ap.add_argument("--distinct-frames", type=int, default=0,
                     help="frame pixel pool size (0 = every frame distinct, as the workload states)")
     return ap.parse_args()
@@ -333,6 +335,65 @@ def c4_sub_result(device, tok_cls):
     return out
 
 
+def train_sub_result(args, device, tok):
+    """BASELINE.json configs[4] on one GPU: one train step (forward under autograd, backward, Adam) over two clips
+    of the headline shape.  The Scallop-derived loss of scripts/train_sgclip.py:781-836 needs scallopy on the host
+    (absent here): a binary cross-entropy of every returned probability against seeded random targets stands in,
+    so that every output carries a gradient."""
+    from laser_amd import training
+    model = PredicateModel(None, None, device, args.model, tokenizer=tok, init_seed=5).enable_training()
+    flat = model.flatten_parameters()
+    opt = training.Adam(flat, lr=1e-6)
+    model.set_recompute_chunk(2048)
+    batch = make_clip_batch(500, n_videos=2, frames=args.frames, objects=args.objects, distinct_frames=8)
+    kw = batch.forward_kwargs()
+    di = model.stage_inputs(kw["batched_videos"], kw["batched_masks"])
+    n_crops = len(kw["batched_object_ids"]) + len(kw["batched_obj_pairs"])
+    gen = torch.Generator(device=device).manual_seed(0)
+
+    def step():
+        cate, unary, binary, dummy = model(**kw, device_inputs=di)
+        loss = 0.0 * dummy
+        for d in [cate[v] for v in cate] + [unary[v] for v in unary] + list(binary):
+            p = d.dense.clamp(1e-6, 1 - 1e-6)
+            t = (torch.rand(p.shape, device=device, generator=gen) < 0.1).float()
+            loss = loss + torch.nn.functional.binary_cross_entropy(p, t)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    step()
+    torch.cuda.synchronize()
+    n = 2
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / n
+    lib = _lib.load()
+    _lib.check(lib.sgclip_timing_enable(1, 65536))
+    step()
+    torch.cuda.synchronize()
+    kinds = {k: timing_read(k) for k in (0, 1, 2, 3, 4, 5, 9)}
+    _lib.check(lib.sgclip_timing_enable(0, 0))
+    g_ms = sum(kinds[k][0] for k in (0, 1, 2, 3, 4))
+    g_fl = sum(kinds[k][2] for k in (0, 1, 2, 3, 4))
+    w_ms, _, w_fl = kinds[5]
+    out = {"workload": f"2 clips x {args.frames} frames x {args.objects} objects x {args.objects * (args.objects - 1)} ordered "
+                       f"pairs/frame at 1280x720, {args.model}, forward + backward + Adam, image towers recomputed in "
+                       f"chunks of 2048 crops during backward, binary cross-entropy stand-in loss",
+           "ms_per_step": ms, "crops_per_s": n_crops / (ms * 1e-3), "crops": n_crops,
+           "gemm_nt_ms": g_ms, "gemm_nt_tflops": g_fl / (g_ms * 1e-3) / 1e12 if g_ms else 0.0,
+           "gemm_tn_weight_grad_ms": w_ms, "gemm_tn_weight_grad_tflops": w_fl / (w_ms * 1e-3) / 1e12 if w_ms else 0.0,
+           "roofline_frac_mfma": (g_fl + w_fl) / ((g_ms + w_ms) * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if g_ms + w_ms else 0.0,
+           "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
+           "note": "GEMM times from HIP events around every launch of one step (forward, recompute, data and weight "
+                   "gradients)"}
+    del model, flat, opt, di
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.force_dist:
@@ -478,6 +539,8 @@ def main():
                                          "concatenates and uploads frames and masks over PCIe; text features cached (eval)"}
     if rank == 0 and world == 1 and not args.no_c4:
         result["c4_l14_336"] = c4_sub_result(device, HashTokenizer)
+    if rank == 0 and world == 1 and not args.no_train:
+        result["train_step"] = train_sub_result(args, device, tok)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         result["cpu_baseline"] = cpu_baseline(args, cfg, sd, tok, batch)

@@ -289,8 +289,9 @@ int sgclip_cast_f32_bf16(const float *in_dev, void *out_dev, int64_t n, void *st
 int sgclip_layernorm_bwd(const float *x_dev, int64_t x_stride, int rows, int d, const float *w_dev, float eps,
                          const void *dy_dev, int dy_dtype, float *dx_dev, int accumulate_dx, float *dw_dev,
                          float *db_dev, void *stream);
-/* Adjoint of sgclip_attention for T <= 128: qkv bf16 [n_seq*T, 3d], dout bf16 [n_seq*T, d]
- * -> dqkv bf16 [n_seq*T, 3d]; the probabilities are recomputed, nothing is saved by the forward. */
+/* Adjoint of sgclip_attention: qkv bf16 [n_seq*T, 3d], dout bf16 [n_seq*T, d] -> dqkv bf16 [n_seq*T, 3d];
+ * the probabilities are recomputed, nothing is saved by the forward.  T <= 128 runs whole sequences per
+ * workgroup, longer ones (up to ~6 000 tokens) a blocked kernel with recomputed row statistics. */
 int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, void *dqkv_dev, int n_seq, int T, int heads,
                          int causal, const int32_t *key_mask_dev, void *stream);
 /* C[M][N] (+)= alpha op(A) op(B), fp32; op(A) = A [M,K] or, transA, A^T with A [K,M]; likewise B.

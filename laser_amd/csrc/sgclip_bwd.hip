@@ -523,6 +523,258 @@ static void attention_bwd_mfma_launch(const bf16_t *qkv, const bf16_t *dout, bf1
 }
 
 // ---------------------------------------------------------------------------
+// The same adjoint for sequences of any length (ViT-L/14 at 336 px: T = 577), in blocks of 64 queries x 64 keys.
+// The forward pass saves nothing, so one workgroup (4 waves) per (sequence, head) makes three sweeps over the
+// block pairs, recomputing S = Q K^T / 8 and dP = dO V^T on the matrix cores each time:
+//   sweep 0  per query row: running maximum m, normaliser l and sum_k exp(S - m) dP (online, rescaled when m moves)
+//            -> m, 1 / l and D = sum_k P dP in LDS
+//   sweep 1  key block outer, query blocks inner: P = exp(S - m) / l, dS = P (dP - D) / 8;
+//            dV += P^T dO, dK += dS^T Q accumulate in registers (wave = 16 keys x 64 channels)
+//   sweep 2  query block outer, key blocks inner: dQ += dS K (wave = 16 queries x 64 channels)
+// Operand blocks live in LDS row-major [64][72] and transposed [64 channels][72]; P^T, dS^T / dS pass through
+// LDS as bf16 to become MFMA operands, as in the short-sequence kernel.  Causal sweeps skip the block pairs
+// above the diagonal.
+// ---------------------------------------------------------------------------
+constexpr int LB = 64, LLD = 72, LBLK = LB * LLD;   // block rows, LDS row stride and block size (bf16 elements)
+
+struct LongBlocks {
+    bf16_t *Qr, *dOr, *Kr, *Vr, *Qt, *dOt, *Kt, *X0, *X1;
+    float *m, *il, *D;
+};
+
+// rows [r0, r0 + 64) of a [T][ld] bf16 matrix (64 channels from column 0) -> row-major and/or transposed LDS blocks
+__device__ __forceinline__ void long_load(const bf16_t *__restrict__ src, size_t ld, int r0, int T, bf16_t *rowmaj,
+                                          bf16_t *transposed) {
+    for (int idx = threadIdx.x; idx < LB * 8; idx += 256) {
+        const int r = idx % LB, ch = idx / LB;
+        bf16x8 v = {};
+        if (r0 + r < T) v = *(const bf16x8 *)(src + (size_t)(r0 + r) * ld + ch * 8);
+        if (rowmaj) *(bf16x8 *)(rowmaj + r * LLD + ch * 8) = v;
+        if (transposed) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) transposed[(ch * 8 + j) * LLD + r] = v[j];
+        }
+    }
+}
+
+// S (scaled, masked with -1e30) and dP of this wave's 16 queries against the 64 keys of the block in LDS:
+// element e of tile ct is query i0 + fq*4 + e (i0 = first query of the wave's tile), key k0 + ct*16 + frow
+__device__ __forceinline__ void long_scores(const LongBlocks &L, int wave, int frow, int fq, int i0, int k0, int T, int causal,
+                                            const int32_t *km, f32x4_t (&S)[4], f32x4_t (&dP)[4]) {
+    bf16x8 aq[2], ao[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; kk++) {
+        aq[kk] = *(const bf16x8 *)(L.Qr + (wave * 16 + frow) * LLD + kk * 32 + fq * 8);
+        ao[kk] = *(const bf16x8 *)(L.dOr + (wave * 16 + frow) * LLD + kk * 32 + fq * 8);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) {
+        S[ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        dP[ct] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const bf16x8 bk = *(const bf16x8 *)(L.Kr + (ct * 16 + frow) * LLD + kk * 32 + fq * 8);
+            const bf16x8 bv = *(const bf16x8 *)(L.Vr + (ct * 16 + frow) * LLD + kk * 32 + fq * 8);
+            S[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[kk], bk, S[ct], 0, 0, 0);
+            dP[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao[kk], bv, dP[ct], 0, 0, 0);
+        }
+        const int k = k0 + ct * 16 + frow;
+        const bool kok = k < T && (!km || km[k < T ? k : 0] != 0);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int i = i0 + fq * 4 + e;
+            const bool ok = kok && (!causal || k <= i);
+            S[ct][e] = ok ? S[ct][e] * 0.125f : -1.0e30f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attention_bwd_long_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+                                                                 bf16_t *__restrict__ dqkv, int T, int heads, int causal,
+                                                                 const int32_t *__restrict__ key_mask) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nb = (T + LB - 1) / LB, TP = nb * LB;
+    LongBlocks L;
+    L.Qr = (bf16_t *)smem; L.dOr = L.Qr + LBLK; L.Kr = L.dOr + LBLK; L.Vr = L.Kr + LBLK;
+    L.Qt = L.Vr + LBLK; L.dOt = L.Qt + LBLK; L.Kt = L.dOt + LBLK; L.X0 = L.Kt + LBLK; L.X1 = L.X0 + LBLK;
+    L.m = (float *)(L.X1 + LBLK); L.il = L.m + TP; L.D = L.il + TP;
+
+    const int d = heads * 64;
+    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
+    const size_t ld = (size_t)3 * d;
+    const bf16_t *qbase = qkv + (size_t)seq * T * ld + head * 64;
+    const bf16_t *dobase = dout + (size_t)seq * T * d + head * 64;
+    bf16_t *obase = dqkv + (size_t)seq * T * ld + head * 64;
+    const int32_t *km = key_mask ? key_mask + (size_t)seq * T : nullptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // ---- sweep 0: row statistics
+    for (int qb = 0; qb < nb; qb++) {
+        __syncthreads();
+        long_load(qbase, ld, qb * LB, T, L.Qr, nullptr);
+        long_load(dobase, (size_t)d, qb * LB, T, L.dOr, nullptr);
+        float m[4], l[4], aD[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) m[e] = -1.0e30f, l[e] = 0.f, aD[e] = 0.f;
+        const int kb_end = causal ? min(nb, qb + 1) : nb;
+        for (int kb = 0; kb < kb_end; kb++) {
+            __syncthreads();
+            long_load(qbase + d, ld, kb * LB, T, L.Kr, nullptr);
+            long_load(qbase + 2 * d, ld, kb * LB, T, L.Vr, nullptr);
+            __syncthreads();
+            f32x4_t S[4], dP[4];
+            long_scores(L, wave, frow, fq, qb * LB + wave * 16, kb * LB, T, causal, km, S, dP);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float bm = fmaxf(fmaxf(S[0][e], S[1][e]), fmaxf(S[2][e], S[3][e]));
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
+                const float mn = fmaxf(m[e], bm);
+                const float sc = __expf(m[e] - mn);
+                float ls = 0.f, ds = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < 4; ct++) {
+                    const float p = S[ct][e] > -0.5e30f ? __expf(S[ct][e] - mn) : 0.f;
+                    ls += p;
+                    ds += p * dP[ct][e];
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    ls += __shfl_xor(ls, o);
+                    ds += __shfl_xor(ds, o);
+                }
+                l[e] = l[e] * sc + ls;
+                aD[e] = aD[e] * sc + ds;
+                m[e] = mn;
+            }
+        }
+        if (frow == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = qb * LB + wave * 16 + fq * 4 + e;
+                const float inv = l[e] > 0.f ? 1.0f / l[e] : 0.f;
+                L.m[i] = m[e];
+                L.il[i] = inv;
+                L.D[i] = aD[e] * inv;
+            }
+        }
+    }
+
+    // ---- sweep 1: dK, dV
+    for (int kb = 0; kb < nb; kb++) {
+        __syncthreads();
+        long_load(qbase + d, ld, kb * LB, T, L.Kr, nullptr);
+        long_load(qbase + 2 * d, ld, kb * LB, T, L.Vr, nullptr);
+        f32x4_t aV[4], aK[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            aV[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            aK[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int qb = causal ? kb : 0; qb < nb; qb++) {
+            __syncthreads();   // the previous pair's products have been read
+            long_load(qbase, ld, qb * LB, T, L.Qr, L.Qt);
+            long_load(dobase, (size_t)d, qb * LB, T, L.dOr, L.dOt);
+            __syncthreads();
+            f32x4_t S[4], dP[4];
+            const int i0 = qb * LB + wave * 16;
+            long_scores(L, wave, frow, fq, i0, kb * LB, T, causal, km, S, dP);
+            float mi[4], ili[4], Di[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                mi[e] = L.m[i0 + fq * 4 + e];
+                ili[e] = L.il[i0 + fq * 4 + e];
+                Di[e] = L.D[i0 + fq * 4 + e];
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ct++) {
+                bf16x4 pp, ps;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float p = S[ct][e] > -0.5e30f ? __expf(S[ct][e] - mi[e]) * ili[e] : 0.f;
+                    pp[e] = (bf16_t)p;
+                    ps[e] = (bf16_t)(p * (dP[ct][e] - Di[e]) * 0.125f);
+                }
+                *(bf16x4 *)(L.X0 + (ct * 16 + frow) * LLD + wave * 16 + fq * 4) = pp;   // P^T  [key][query]
+                *(bf16x4 *)(L.X1 + (ct * 16 + frow) * LLD + wave * 16 + fq * 4) = ps;   // dS^T [key][query]
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s0 = 0; s0 < LB; s0 += 32) {
+                const bf16x8 fp = *(const bf16x8 *)(L.X0 + (wave * 16 + frow) * LLD + s0 + fq * 8);
+                const bf16x8 fst = *(const bf16x8 *)(L.X1 + (wave * 16 + frow) * LLD + s0 + fq * 8);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const bf16x8 bo = *(const bf16x8 *)(L.dOt + (c * 16 + frow) * LLD + s0 + fq * 8);
+                    const bf16x8 bq = *(const bf16x8 *)(L.Qt + (c * 16 + frow) * LLD + s0 + fq * 8);
+                    aV[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp, bo, aV[c], 0, 0, 0);
+                    aK[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fst, bq, aK[c], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int t = kb * LB + wave * 16 + fq * 4 + e;
+            if (t >= T) continue;
+            bf16_t *o = obase + (size_t)t * ld + frow;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                o[d + c * 16] = (bf16_t)aK[c][e];
+                o[2 * d + c * 16] = (bf16_t)aV[c][e];
+            }
+        }
+    }
+
+    // ---- sweep 2: dQ
+    for (int qb = 0; qb < nb; qb++) {
+        __syncthreads();
+        long_load(qbase, ld, qb * LB, T, L.Qr, nullptr);
+        long_load(dobase, (size_t)d, qb * LB, T, L.dOr, nullptr);
+        f32x4_t aQ[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) aQ[c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const int i0 = qb * LB + wave * 16;
+        const int kb_end = causal ? min(nb, qb + 1) : nb;
+        for (int kb = 0; kb < kb_end; kb++) {
+            __syncthreads();
+            long_load(qbase + d, ld, kb * LB, T, L.Kr, L.Kt);
+            long_load(qbase + 2 * d, ld, kb * LB, T, L.Vr, nullptr);
+            __syncthreads();
+            f32x4_t S[4], dP[4];
+            long_scores(L, wave, frow, fq, i0, kb * LB, T, causal, km, S, dP);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float mi = L.m[i0 + fq * 4 + e], ili = L.il[i0 + fq * 4 + e], Di = L.D[i0 + fq * 4 + e];
+#pragma unroll
+                for (int ct = 0; ct < 4; ct++) {
+                    const float p = S[ct][e] > -0.5e30f ? __expf(S[ct][e] - mi) * ili : 0.f;
+                    L.X0[(wave * 16 + fq * 4 + e) * LLD + ct * 16 + frow] = (bf16_t)(p * (dP[ct][e] - Di) * 0.125f);   // dS [query][key]
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s0 = 0; s0 < LB; s0 += 32) {
+                const bf16x8 fs = *(const bf16x8 *)(L.X0 + (wave * 16 + frow) * LLD + s0 + fq * 8);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const bf16x8 bk = *(const bf16x8 *)(L.Kt + (c * 16 + frow) * LLD + s0 + fq * 8);
+                    aQ[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fs, bk, aQ[c], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int t = i0 + fq * 4 + e;
+            if (t >= T) continue;
+            bf16_t *o = obase + (size_t)t * ld + frow;
+#pragma unroll
+            for (int c = 0; c < 4; c++) o[c * 16] = (bf16_t)aQ[c][e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // C[M][N] (+)= alpha * op(A) op(B), fp32, 64 x 64 tiles (the small products of the fp32 tail:
 // projection, similarity).  op(A) is [M][K]: A[m][k] or, transposed, A[k][m]; likewise op(B) [K][N].
 // ---------------------------------------------------------------------------
@@ -766,8 +1018,23 @@ extern "C" int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, v
     if (n_seq == 0) return SGCLIP_OK;
     BWD_ARGS_OK(qkv_dev && dout_dev && dqkv_dev && n_seq > 0 && T > 0 && heads > 0, "sgclip_attention_bwd");
     if (T > 128) {
-        set_error("sgclip_attention_bwd: T=%d > 128 is not supported by the short-sequence backward kernel", T);
-        return SGCLIP_EINVAL;
+        // long sequences: blocked kernel with recomputed statistics
+        const int TP = (T + LB - 1) / LB * LB;
+        const size_t lds = (size_t)9 * LBLK * sizeof(bf16_t) + (size_t)3 * TP * sizeof(float);
+        if (lds > 160 * 1024 || ((uintptr_t)qkv_dev & 15) || ((uintptr_t)dout_dev & 15)) {
+            set_error("sgclip_attention_bwd: T=%d too long for the per-row statistics to fit the LDS, or operands not "
+                      "16-byte aligned", T);
+            return SGCLIP_EINVAL;
+        }
+        static bool attr_long = false;
+        if (!attr_long) {
+            (void)hipFuncSetAttribute((const void *)attention_bwd_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            attr_long = true;
+        }
+        hipLaunchKernelGGL(attention_bwd_long_kernel, dim3((unsigned)(n_seq * heads)), dim3(256), lds, (hipStream_t)stream,
+                           (const bf16_t *)qkv_dev, (const bf16_t *)dout_dev, (bf16_t *)dqkv_dev, T, heads, causal, key_mask_dev);
+        return launch_check("sgclip_attention_bwd");
     }
     static int use_valu = -1;   // SGCLIP_ATTN_BWD_VALU=1: the plain VALU kernel (cross-check)
     if (use_valu < 0) {
