@@ -99,10 +99,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_kernel(AttnArgs a) {
         for (int s = 0; s < 4; s++) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
 
         bf16x8 pb[2];
+        float alpha;
         if (n0 + 32 > T || kmask || (a.causal && n0 + 31 > m0))
-            online_softmax_step<true>(st, m_run, l_run, o0, o1, pb, n0, m, h, T, a.causal, kmask);
+            alpha = online_softmax_step<true>(st, m_run, l_run, pb, n0, m, h, T, a.causal, kmask);
         else
-            online_softmax_step<false>(st, m_run, l_run, o0, o1, pb, n0, m, h, T, a.causal, kmask);
+            alpha = online_softmax_step<false>(st, m_run, l_run, pb, n0, m, h, T, a.causal, kmask);
+        if (__ballot(alpha != 1.0f)) {
+            scale_acc(o0, alpha);
+            scale_acc(o1, alpha);
+        }
 
         if (pooled) {  // V tile written by all lanes of this wave
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -155,7 +160,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_kernel(AttnArgs a) {
 // the L2 -> CU path once per 128 queries instead of once per 32.
 // K tile image: [32 keys][128 B], 16-byte chunks XOR-swizzled with (key & 7) so that the
 // ds_read_b128 fragment reads (32 keys x one chunk per half wave) are conflict free.
-// V tile image: plain [32 keys][64], read transposed with ds_read_b64_tr_b16 as above.
+// V tile image: [32 keys][64] with the 16-byte chunk index XORed by 4 on rows 2, 3 mod 4, read transposed with
+// ds_read_b64_tr_b16 (conflict free).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_shared_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t kt[2][32 * 64];
@@ -202,53 +208,93 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_shared_kernel(AttnArgs
     };
     auto stash = [&](int buf, const bf16x8 &kreg, const bf16x8 &vreg) {
         *(bf16x8 *)(kt[buf] + lrow * 64 + ((lchunk ^ (lrow & 7)) << 3)) = kreg;
-        *(bf16x8 *)(vts[buf] + lrow * 64 + lchunk * 8) = vreg;
+        *(bf16x8 *)(vts[buf] + lrow * 64 + ((lchunk ^ (((lrow >> 1) & 1) << 2)) << 3)) = vreg;
     };
     bf16x8 kreg, vreg;
     fetch(0, kreg, vreg);
     stash(0, kreg, vreg);
+    // The query fragments are "used" here so that their loads have landed, as far as the compiler's wait-count
+    // bookkeeping knows, before the loop starts: with one of them possibly in flight at the loop head it waits where
+    // the loop first reads those registers, in every iteration, and since the load counter retires in order that wait
+    // also drains the K / V block just prefetched -- the whole global latency exposed per key block.
+    asm volatile("" ::"v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]) : "memory");
     if (n_blocks > 1) fetch(1, kreg, vreg);
     __syncthreads();
 
-    for (int kb = 0; kb < n_blocks; kb++) {
+    // Two loops with one barrier per iteration each: the blocks this wave scores, then (causal towers, waves past the
+    // end of the sequence) the blocks it only helps to load.  A single loop with the scoring under a condition makes
+    // the compiler keep the 32 output accumulators in two register ranges and copy them back and forth every block.
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int tq = i16 >> 2, tp = i16 & 3;
+    int kb = 0;
+    for (; kb < my_blocks; kb++) {
         const int n0 = kb * 32;
         const bf16_t *kcur = kt[kb & 1], *vcur = vts[kb & 1];
-        if (kb < my_blocks) {
-            bf16x8 kf[4];
+        bf16x8 kf[4];
 #pragma unroll
-            for (int s = 0; s < 4; s++) kf[s] = *(const bf16x8 *)(kcur + r * 64 + (((2 * s + h) ^ (r & 7)) << 3));
-            f32x16 st;
+        for (int s = 0; s < 4; s++) kf[s] = *(const bf16x8 *)(kcur + r * 64 + (((2 * s + h) ^ (r & 7)) << 3));
+        f32x16 st;
 #pragma unroll
-            for (int g = 0; g < 16; g++) st[g] = 0.f;
+        for (int g = 0; g < 16; g++) st[g] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; s++) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
+        for (int s = 0; s < 4; s++) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
 
-            bf16x8 pb[2];
-            if (n0 + 32 > T || kmask || (a.causal && n0 + 31 > m0))
-                online_softmax_step<true>(st, m_run, l_run, o0, o1, pb, n0, m, h, T, a.causal, kmask);
-            else
-                online_softmax_step<false>(st, m_run, l_run, o0, o1, pb, n0, m, h, T, a.causal, kmask);
+        bf16x8 pb[2];
+#if defined(ATTN_ABLATE) && (ATTN_ABLATE & 1)   // diagnostic: no softmax arithmetic
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) pb[s2][j] = (bf16_t)st[8 * s2 + j];
+        l_run += 1.0f;
+#else
+        float alpha;
+        if (n0 + 32 > T || kmask || (a.causal && n0 + 31 > m0))
+            alpha = online_softmax_step<true>(st, m_run, l_run, pb, n0, m, h, T, a.causal, kmask);
+        else
+            alpha = online_softmax_step<false>(st, m_run, l_run, pb, n0, m, h, T, a.causal, kmask);
+        if (__ballot(alpha != 1.0f)) {
+            scale_acc(o0, alpha);
+            scale_acc(o1, alpha);
+        }
+#endif
 
-            const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-            const int tq = i16 >> 2, tp = i16 & 3;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) {
+        for (int s2 = 0; s2 < 2; s2++) {
 #pragma unroll
-                for (int dt = 0; dt < 2; dt++) {
-                    const bf16_t *p0 = vcur + (16 * s2 + 4 * h + tq) * 64 + 32 * dt + 16 * g16 + 4 * tp;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)p0);
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(p0 + 8 * 64));
-                    bf16x8 vf;
-                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+            for (int dt = 0; dt < 2; dt++) {
+#if defined(ATTN_ABLATE) && (ATTN_ABLATE & 2)   // diagnostic: V fragments from the (conflict-free) K image, plain reads
+                {
+                    const bf16x8 vk = *(const bf16x8 *)(kcur + r * 64 + (((2 * s2 + dt * 4 + h) ^ (r & 7)) << 3));
                     if (dt == 0)
-                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s2], o0, 0, 0, 0);
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vk, pb[s2], o0, 0, 0, 0);
                     else
-                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s2], o1, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vk, pb[s2], o1, 0, 0, 0);
+                    continue;
                 }
+#endif
+                // 16-byte chunk XORed with 4 on rows 2, 3 mod 4: the four rows x 64 bytes a half wave reads then cover
+                // all 64 banks once (rows are 128 bytes = half the bank array, so rows two apart would collide)
+                const int vrow = 16 * s2 + 4 * h + tq;
+                const bf16_t *p0 = vcur + vrow * 64 + (((4 * dt + 2 * g16 + (tp >> 1)) ^ (((vrow >> 1) & 1) << 2)) << 3) + 4 * (tp & 1);
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)p0);
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4 *)(p0 + 8 * 64));
+                bf16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                if (dt == 0)
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s2], o0, 0, 0, 0);
+                else
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s2], o1, 0, 0, 0);
             }
         }
         // the other buffer was last read in the previous iteration, which every wave has left
+#if !(defined(ATTN_ABLATE) && (ATTN_ABLATE & 4))   // diagnostic: one K / V block reused, no refill, no barrier
+        if (kb + 1 < n_blocks) stash((kb + 1) & 1, kreg, vreg);
+        if (kb + 2 < n_blocks) fetch(kb + 2, kreg, vreg);
+        __syncthreads();
+#endif
+    }
+    for (; kb < n_blocks; kb++) {
         if (kb + 1 < n_blocks) stash((kb + 1) & 1, kreg, vreg);
         if (kb + 2 < n_blocks) fetch(kb + 2, kreg, vreg);
         __syncthreads();

@@ -220,10 +220,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs g) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s4], qf[s4], st, 0, 0, 0);
             bf16x8 pb[2];
+            float alpha;
             if (n0 + 32 > T)
-                online_softmax_step<true>(st, m_run, l_run, o0, o1, pb, n0, m, h, T, false, nullptr);
+                alpha = online_softmax_step<true>(st, m_run, l_run, pb, n0, m, h, T, false, nullptr);
             else
-                online_softmax_step<false>(st, m_run, l_run, o0, o1, pb, n0, m, h, T, false, nullptr);
+                alpha = online_softmax_step<false>(st, m_run, l_run, pb, n0, m, h, T, false, nullptr);
+            if (__ballot(alpha != 1.0f)) {
+                scale_acc(o0, alpha);
+                scale_acc(o1, alpha);
+            }
             // V^T fragments: element j of k-step s2 is V[n0 + 16 s2 + 8 (j>>2) + 4 h + (j&3)][32 dt + r]; keys past the
             // sequence carry probability 0, their rows are clamped so that only finite values are multiplied by it
 #pragma unroll

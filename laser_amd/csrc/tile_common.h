@@ -26,11 +26,12 @@ constexpr float NEG_BIG = -1.0e30f;
 // st: S^T accumulators of this lane's query (register g = key n0 + (g&3) + 8*(g>>2) + 4*h); on
 // return pb holds exp2(score - running max) as the bf16 B operand of O^T += V^T * P^T.
 // MASKED = false is the interior-block path: every key valid, no comparisons.
-// The output accumulators are rescaled only when some lane's running maximum moved.
+// Returns the factor the caller scales its output accumulators by (1 where the running maximum did not move).  The
+// accumulators are deliberately not touched in here: updating them under this function's branches makes the compiler
+// keep them in two register ranges and copy all 32 registers back and forth on every key block.
 template <bool MASKED>
-__device__ __forceinline__ void online_softmax_step(f32x16 &st, float &m_run, float &l_run, f32x16 &o0, f32x16 &o1,
-                                                    bf16x8 (&pb)[2], int n0, int m, int h, int T, bool causal,
-                                                    const int32_t *kmask) {
+__device__ __forceinline__ float online_softmax_step(f32x16 &st, float &m_run, float &l_run, bf16x8 (&pb)[2], int n0, int m,
+                                                     int h, int T, bool causal, const int32_t *kmask) {
     constexpr float C = 0.125f * 1.4426950408889634f;
     float mx = NEG_BIG;
     float m_new;
@@ -71,21 +72,27 @@ __device__ __forceinline__ void online_softmax_step(f32x16 &st, float &m_run, fl
         }
     }
     psum += __shfl_xor(psum, 32, 64);
-    if (__ballot(m_new != m_run)) {
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            o0[g] *= alpha;
-            o1[g] *= alpha;
-        }
-        m_run = m_new;
-    }
-    l_run += psum;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
 #pragma unroll
     for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
         for (int j = 0; j < 8; j++) pb[s2][j] = (bf16_t)st[8 * s2 + j];
+    return alpha;
+}
+
+// o *= alpha on the packed fp32 multiplier (two registers per instruction)
+__device__ __forceinline__ void scale_acc(f32x16 &o, float alpha) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 a2 = {alpha, alpha};
+#pragma unroll
+    for (int g = 0; g < 16; g += 2) {
+        f32x2 v = {o[g], o[g + 1]};
+        v = v * a2;
+        o[g] = v[0];
+        o[g + 1] = v[1];
+    }
 }
 
 }  // namespace sgclip
