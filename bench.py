@@ -200,12 +200,14 @@ def score_clip(model: PredicateModel, plan: ClipPlan, concurrent: bool = True):
 
 def pmc_traffic(substr):
     """Average HBM bytes per launch of the kernels whose name contains `substr`, from the
-    rocprofv3 PMC passes over this same command (profiles/r01_pmc_bench_traffic.json:
+    rocprofv3 PMC passes over this same command (the newest profiles/r*_pmc_bench_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as gfx950
-    requires for wide streaming reads).  None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")
-    if not os.path.exists(path):
+    requires for wide streaming reads).  None when no such file exists."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_traffic.json")))
+    if not found:
         return None
+    path = found[-1]
     ks = json.load(open(path))["kernels"]
     subs = (substr,) if isinstance(substr, str) else tuple(substr)
     tot = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for k, v in ks.items() if any(s in k for s in subs))
