@@ -240,20 +240,30 @@ class PredicateModel(nn.Module):
         """Upload frames (u8[H,W,3]) and masks (anything `.astype(bool)` accepts, [H,W,1]
         or [H,W]; or a `laser_amd.masks.PackedMasks`, uploaded as bits and expanded on the
         GPU) into two flat device buffers."""
-        frame_off, frame_hw, chunks, off = [], [], [], 0
+        # Frames and masks go into pinned host buffers that persist across calls (one pass over the bytes, no
+        # concatenated temporary) and from there to the device with one asynchronous copy each.
+        frame_off, frame_hw, off = [], [], 0
+        arrs = []
         for f in batched_videos:
-            f = np.ascontiguousarray(f)
+            f = np.asarray(f)
             if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3:
                 raise ValueError(f"frames must be uint8 [H,W,3], got {f.dtype} {f.shape}")
-            frame_off.append(off); frame_hw.append((f.shape[0], f.shape[1])); chunks.append(f.reshape(-1))
+            frame_off.append(off); frame_hw.append((f.shape[0], f.shape[1])); arrs.append(f)
             off += f.size
-        chunks.append(np.zeros(ops.PAD, dtype=np.uint8))
-        frames = torch.from_numpy(np.concatenate(chunks)).to(self.device, non_blocking=True)
+        host = self._pinned("frames", off + ops.PAD)
+        hv = host.numpy()
+        for f, o in zip(arrs, frame_off):
+            np.copyto(hv[o:o + f.size].reshape(f.shape), f)
+        hv[off:off + ops.PAD] = 0
+        frames = torch.empty(off + ops.PAD, dtype=torch.uint8, device=self.device)
+        frames.copy_(host[:off + ops.PAD], non_blocking=True)
+        self._pinned_done("frames")
         if isinstance(batched_masks, PackedMasks):
             un = unpack_to_device(batched_masks, self.device)
             return DeviceInputs(frames, frame_off, frame_hw, un.masks if len(batched_masks) else None, un.offsets,
                                 un.ndims, unpacked=un, mask_hw=un.shapes)
-        mask_off, mask_ndim, mask_hw, mchunks, off = [], [], [], [], 0
+        mask_off, mask_ndim, mask_hw, off = [], [], [], 0
+        arrs = []
         for m in batched_masks:
             m = np.asarray(m)
             mask_ndim.append(m.ndim)
@@ -264,14 +274,42 @@ class PredicateModel(nn.Module):
             elif m.ndim != 2:
                 raise ValueError(f"masks must be [H,W,1] or [H,W], got {m.shape}")
             mask_hw.append((m.shape[0], m.shape[1]))
-            m = np.ascontiguousarray(m.astype(bool)).view(np.uint8)
-            mask_off.append(off); mchunks.append(m.reshape(-1))
+            mask_off.append(off); arrs.append(m)
             off += m.size
         masks = None
-        if mchunks:
-            mchunks.append(np.zeros(ops.PAD, dtype=np.uint8))
-            masks = torch.from_numpy(np.concatenate(mchunks)).to(self.device, non_blocking=True)
+        if arrs:
+            host = self._pinned("masks", off + ops.PAD)
+            hv = host.numpy()
+            for m, o in zip(arrs, mask_off):
+                dst = hv[o:o + m.size].reshape(m.shape)
+                if m.dtype == np.bool_:
+                    np.copyto(dst, m.view(np.uint8))
+                else:
+                    np.not_equal(m, 0, out=dst.view(np.bool_))      # .astype(bool) of the reference (model_utils.py:34)
+            hv[off:off + ops.PAD] = 0
+            masks = torch.empty(off + ops.PAD, dtype=torch.uint8, device=self.device)
+            masks.copy_(host[:off + ops.PAD], non_blocking=True)
+            self._pinned_done("masks")
         return DeviceInputs(frames, frame_off, frame_hw, masks, mask_off, mask_ndim, mask_hw=mask_hw)
+
+    def _pinned(self, name: str, nbytes: int) -> torch.Tensor:
+        """A pinned host staging buffer of at least `nbytes`, free to be overwritten (the copy that last read it
+        has finished)."""
+        bufs = self.__dict__.setdefault("_pinned_bufs", {})
+        buf, ev = bufs.get(name, (None, None))
+        if ev is not None:
+            ev.synchronize()
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        bufs[name] = (buf, None)
+        return buf
+
+    def _pinned_done(self, name: str):
+        """Marks the point in the current stream after which the staging buffer `name` may be reused."""
+        buf, _ = self._pinned_bufs[name]
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._pinned_bufs[name] = (buf, ev)
 
     def _text_features(self, prefix: str, kws: Sequence[str]) -> torch.Tensor:
         if self._grad_mode():
