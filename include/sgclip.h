@@ -223,14 +223,19 @@ int sgclip_mask_unpack(const uint8_t *packed_dev, size_t packed_bytes, const sgc
  * ---------------------------------------------------------------------- */
 #define SGCLIP_EPI_BIAS_BF16 0      /* C_bf16 = A W^T + bias                   */
 #define SGCLIP_EPI_BIAS_GELU_BF16 1 /* C_bf16 = quick_gelu(A W^T + bias)       */
-#define SGCLIP_EPI_BIAS_RESID_F32 2 /* C_f32 += A W^T + bias (in place)        */
+#define SGCLIP_EPI_BIAS_RESID_F32 2 /* C_f32 = R + A W^T + bias; R = aux (f32 [M, N], row stride ldc) or, aux NULL, C itself */
 #define SGCLIP_EPI_PATCH_F32 3      /* C_f32[(m/P)*T + 1 + m%P] = A W^T + aux[(1 + m%P)]  (aux = pos emb, P = aux_rows) */
 #define SGCLIP_EPI_F32 4            /* C_f32 = A W^T                           */
 #define SGCLIP_EPI_F32_ATOMIC 5     /* C_f32 += A W^T, the K range split over several workgroups that add their
                                      * partial tiles with fp32 atomics (weight gradients: few tiles, very long K) */
-/* A: bf16 [M, K] (lda), W: bf16 [N, K] (ldw), C: [.., N] (ldc); K % 64 == 0.  */
+/* The two halves of the MLP activation of the train step (modeling_clip.py:346-350 under autograd): */
+#define SGCLIP_EPI_BIAS_GELU_BOTH_BF16 6   /* C_bf16 = u = A W^T + bias AND aux (bf16 [M, N], row stride ldc, WRITTEN)
+                                            * = quick_gelu(u): the pre-activation the backward pass keeps and fc2's input */
+#define SGCLIP_EPI_BIAS_MULGELUGRAD_BF16 7 /* C_bf16 = (A W^T + bias) * quick_gelu'(u), u = aux (bf16 [M, N], row stride
+                                            * ldc): the data gradient through fc2 and the activation in one pass */
+/* A: bf16 [M, K] (lda), W: bf16 [N, K] (ldw), C: [.., N] (ldc); K % 64 == 0.  aux_dev: see the epilogue. */
 int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, int ldw, void *C_dev, int ldc, int M, int N,
-                     int K, int epilogue, const float *bias_dev, const float *aux_dev, int aux_rows,
+                     int K, int epilogue, const float *bias_dev, const void *aux_dev, int aux_rows,
                      void *stream);
 /* y[rows, out] = x[rows, in] * w[out, in]^T for fp32 operands, each split into bf16
  * hi + lo halves on the MFMA (three products), error ~2^-16 relative; in % 16 == 0. */

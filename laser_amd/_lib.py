@@ -20,6 +20,7 @@ LAYOUT_CHW, LAYOUT_PATCHES = 0, 1
 DTYPE_F32, DTYPE_BF16 = 0, 1
 SIM_LOGIT, SIM_SOFTMAX, SIM_SIGMOID = 0, 1, 2
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_RESID_F32, EPI_PATCH_F32, EPI_F32, EPI_F32_ATOMIC = 0, 1, 2, 3, 4, 5
+EPI_BIAS_GELU_BOTH_BF16, EPI_BIAS_MULGELUGRAD_BF16 = 6, 7
 CROP_LUT_BYTES = 768 + 768 * 4
 
 (T_PATCH_W, T_CLS, T_POS, T_PRE_LN_W, T_PRE_LN_B, T_LN1_W, T_LN1_B, T_QKV_W, T_QKV_B, T_O_W, T_O_B, T_LN2_W,

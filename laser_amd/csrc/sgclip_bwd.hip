@@ -122,9 +122,18 @@ __global__ __launch_bounds__(256) void dot_f32_kernel(const float *__restrict__ 
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
+// eight elements per thread (two 16-byte loads, one 16-byte store), scalar tail
 __global__ void cast_f32_bf16_kernel(const float *__restrict__ in, bf16_t *__restrict__ out, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (bf16_t)in[i];
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const float4 a = *(const float4 *)(in + i), b = *(const float4 *)(in + i + 4);
+        bf16x8 y;
+        y[0] = (bf16_t)a.x; y[1] = (bf16_t)a.y; y[2] = (bf16_t)a.z; y[3] = (bf16_t)a.w;
+        y[4] = (bf16_t)b.x; y[5] = (bf16_t)b.y; y[6] = (bf16_t)b.z; y[7] = (bf16_t)b.w;
+        *(bf16x8 *)(out + i) = y;
+    } else {
+        for (long long j = i; j < n; j++) out[j] = (bf16_t)in[j];
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -971,8 +980,9 @@ extern "C" int sgclip_quick_gelu_bwd(const void *u_dev, const void *dg_dev, void
 
 extern "C" int sgclip_cast_f32_bf16(const float *in_dev, void *out_dev, int64_t n, void *stream) {
     if (n == 0) return SGCLIP_OK;
-    BWD_ARGS_OK(in_dev && out_dev && n > 0, "sgclip_cast_f32_bf16");
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in_dev,
+    BWD_ARGS_OK(in_dev && out_dev && n > 0 && !((uintptr_t)in_dev & 15) && !((uintptr_t)out_dev & 15),
+                "sgclip_cast_f32_bf16 (16-byte alignment)");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, in_dev,
                        (bf16_t *)out_dev, (long long)n);
     return launch_check("sgclip_cast_f32_bf16");
 }

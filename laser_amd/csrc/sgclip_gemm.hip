@@ -61,6 +61,23 @@ __device__ __forceinline__ float quick_gelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x));
 }
 
+// d/dx of x * sigmoid(1.702 x)
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * x));
+    return s + 1.702f * x * s * (1.0f - s);
+}
+
+constexpr int EPI_GELU_BOTH = SGCLIP_EPI_BIAS_GELU_BOTH_BF16, EPI_MULGRAD = SGCLIP_EPI_BIAS_MULGELUGRAD_BF16;
+template <int EPI>
+constexpr bool epi_has_bias() {
+    return EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16 || EPI == SGCLIP_EPI_BIAS_RESID_F32 || EPI == EPI_GELU_BOTH ||
+           EPI == EPI_MULGRAD;
+}
+template <int EPI>
+constexpr bool epi_bf16_out() {
+    return EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16 || EPI == EPI_GELU_BOTH || EPI == EPI_MULGRAD;
+}
+
 // split-K launches: workgroup row blockIdx.y owns K range [y * g.K, min((y + 1) * g.K, k_total))
 __device__ __forceinline__ void split_k_setup(GemmArgs &g) {
     const int k0 = blockIdx.y * g.K;
@@ -102,8 +119,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, const f32x4 (&acc)[4
         const int n = nw + j * 16 + frow;
         if (n >= g.N) continue;
         float bias = 0.f;
-        if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16 || EPI == SGCLIP_EPI_BIAS_RESID_F32)
-            bias = g.bias[n];
+        if (epi_has_bias<EPI>()) bias = g.bias[n];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -115,9 +131,15 @@ __device__ __forceinline__ void epilogue(const GemmArgs &g, const f32x4 (&acc)[4
                     ((bf16_t *)g.C)[(size_t)m * g.ldc + n] = (bf16_t)v;
                 } else if (EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
                     ((bf16_t *)g.C)[(size_t)m * g.ldc + n] = (bf16_t)quick_gelu(v);
+                } else if (EPI == EPI_GELU_BOTH) {
+                    ((bf16_t *)g.C)[(size_t)m * g.ldc + n] = (bf16_t)v;
+                    ((bf16_t *)g.aux)[(size_t)m * g.ldc + n] = (bf16_t)quick_gelu((float)(bf16_t)v);
+                } else if (EPI == EPI_MULGRAD) {
+                    ((bf16_t *)g.C)[(size_t)m * g.ldc + n] =
+                        (bf16_t)(v * quick_gelu_grad((float)((const bf16_t *)g.aux)[(size_t)m * g.ldc + n]));
                 } else if (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
-                    float *p = (float *)g.C + (size_t)m * g.ldc + n;
-                    *p = *p + v;
+                    const size_t o = (size_t)m * g.ldc + n;
+                    ((float *)g.C)[o] = (g.aux ? g.aux[o] : ((float *)g.C)[o]) + v;
                 } else if (EPI == SGCLIP_EPI_PATCH_F32) {
                     const int P = g.aux_rows;
                     const int img = m / P, pp = m - img * P;
@@ -164,8 +186,7 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs &g, const f32x4 (&ac
     const int n = nw + c4;
     if (n >= g.N) return;  // N is a multiple of 4 wherever this epilogue is used
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16 || EPI == SGCLIP_EPI_BIAS_RESID_F32)
-        bias = *(const float4 *)(g.bias + n);
+    if (epi_has_bias<EPI>()) bias = *(const float4 *)(g.bias + n);
 #pragma unroll 4
     for (int rr = 0; rr < 16; rr++) {
         const int row = rr * 4 + r0;
@@ -173,16 +194,27 @@ __device__ __forceinline__ void epilogue_lds(const GemmArgs &g, const f32x4 (&ac
         if (m >= g.M) continue;
         float4 v = *(const float4 *)(region + row * EPI_LD + c4);
         v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-        if (EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
+        if (epi_bf16_out<EPI>()) {
             if (EPI == SGCLIP_EPI_BIAS_GELU_BF16) {
                 v.x = quick_gelu(v.x); v.y = quick_gelu(v.y); v.z = quick_gelu(v.z); v.w = quick_gelu(v.w);
+            }
+            if (EPI == EPI_MULGRAD) {
+                const bf16x4 u = *(const bf16x4 *)((const bf16_t *)g.aux + (size_t)m * g.ldc + n);
+                v.x *= quick_gelu_grad((float)u[0]); v.y *= quick_gelu_grad((float)u[1]);
+                v.z *= quick_gelu_grad((float)u[2]); v.w *= quick_gelu_grad((float)u[3]);
             }
             bf16x4 o;
             o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
             *(bf16x4 *)((bf16_t *)g.C + (size_t)m * g.ldc + n) = o;
+            if (EPI == EPI_GELU_BOTH) {
+                bf16x4 a;
+#pragma unroll
+                for (int q = 0; q < 4; q++) a[q] = (bf16_t)quick_gelu((float)o[q]);
+                *(bf16x4 *)((bf16_t *)g.aux + (size_t)m * g.ldc + n) = a;
+            }
         } else if (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
             float4 *p = (float4 *)((float *)g.C + (size_t)m * g.ldc + n);
-            const float4 c = *p;
+            const float4 c = g.aux ? *(const float4 *)(g.aux + (size_t)m * g.ldc + n) : *p;
             *p = make_float4(c.x + v.x, c.y + v.y, c.z + v.z, c.w + v.w);
         } else if (EPI == SGCLIP_EPI_PATCH_F32) {
             const int P = g.aux_rows;
@@ -373,7 +405,7 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
         }
         return;
     }
-    constexpr bool BF = EPI == SGCLIP_EPI_BIAS_BF16 || EPI == SGCLIP_EPI_BIAS_GELU_BF16;
+    constexpr bool BF = epi_bf16_out<EPI>();
     constexpr int CPL = BF ? 8 : 4;                // columns per lane
     constexpr int LPR = NJ * 16 / CPL;             // lanes per row
     constexpr int RPI = 64 / LPR;                  // rows per store instruction
@@ -383,7 +415,7 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
     float bias[CPL];
 #pragma unroll
     for (int q = 0; q < CPL; q++) bias[q] = 0.f;
-    if ((BF || EPI == SGCLIP_EPI_BIAS_RESID_F32) && n < g.N) {   // the wide epilogue needs N % 8 == 0
+    if (epi_has_bias<EPI>() && n < g.N) {   // the wide epilogue needs N % 8 == 0
 #pragma unroll
         for (int q = 0; q < CPL; q += 4) {
             const float4 b = *(const float4 *)(g.bias + n + q);
@@ -412,12 +444,24 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
             if (m >= g.M || n >= g.N) continue;
             if constexpr (BF) {
                 bf16x8 o;
+                if constexpr (EPI == EPI_MULGRAD) {
+                    const bf16x8 u = *(const bf16x8 *)((const bf16_t *)g.aux + (size_t)m * g.ldc + n);
 #pragma unroll
-                for (int q = 0; q < 8; q++) o[q] = (bf16_t)(EPI == SGCLIP_EPI_BIAS_GELU_BF16 ? quick_gelu(v[q]) : v[q]);
+                    for (int q = 0; q < 8; q++) o[q] = (bf16_t)(v[q] * quick_gelu_grad((float)u[q]));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) o[q] = (bf16_t)(EPI == SGCLIP_EPI_BIAS_GELU_BF16 ? quick_gelu(v[q]) : v[q]);
+                }
                 *(bf16x8 *)((bf16_t *)g.C + (size_t)m * g.ldc + n) = o;
+                if constexpr (EPI == EPI_GELU_BOTH) {
+                    bf16x8 a;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) a[q] = (bf16_t)quick_gelu((float)o[q]);
+                    *(bf16x8 *)((bf16_t *)g.aux + (size_t)m * g.ldc + n) = a;
+                }
             } else if constexpr (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
                 float4 *p = (float4 *)((float *)g.C + (size_t)m * g.ldc + n);
-                const float4 c = *p;
+                const float4 c = g.aux ? *(const float4 *)(g.aux + (size_t)m * g.ldc + n) : *p;
                 *p = make_float4(c.x + v[0], c.y + v[1], c.z + v[2], c.w + v[3]);
             } else if constexpr (EPI == SGCLIP_EPI_PATCH_F32) {
                 const int P = g.aux_rows;
@@ -1014,8 +1058,9 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
 using namespace sgclip;
 
 extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, int ldw, void *C_dev, int ldc, int M,
-                                int N, int K, int epilogue, const float *bias_dev, const float *aux_dev, int aux_rows,
+                                int N, int K, int epilogue, const float *bias_dev, const void *aux_void, int aux_rows,
                                 void *stream_) {
+    const float *aux_dev = (const float *)aux_void;
     hipStream_t stream = (hipStream_t)stream_;
     if (M == 0 || N == 0) return SGCLIP_OK;
     if (!A_dev || !W_dev || !C_dev || M < 0 || N < 0 || K <= 0 || K % BK != 0 || lda < K || ldw < K || ldc < N) {
@@ -1028,8 +1073,9 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
         return SGCLIP_EINVAL;
     }
     const bool needs_bias = epilogue == SGCLIP_EPI_BIAS_BF16 || epilogue == SGCLIP_EPI_BIAS_GELU_BF16 ||
-                            epilogue == SGCLIP_EPI_BIAS_RESID_F32;
-    if ((needs_bias && !bias_dev) || (epilogue == SGCLIP_EPI_PATCH_F32 && (!aux_dev || aux_rows <= 0))) {
+                            epilogue == SGCLIP_EPI_BIAS_RESID_F32 || epilogue == EPI_GELU_BOTH || epilogue == EPI_MULGRAD;
+    const bool needs_aux = epilogue == EPI_GELU_BOTH || epilogue == EPI_MULGRAD;
+    if ((needs_bias && !bias_dev) || (epilogue == SGCLIP_EPI_PATCH_F32 && (!aux_dev || aux_rows <= 0)) || (needs_aux && !aux_dev)) {
         set_error("sgclip_gemm_bf16: epilogue %d needs bias/aux", epilogue);
         return SGCLIP_EINVAL;
     }
@@ -1062,11 +1108,14 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
     }
     g.wide_epilogue = (N % 8 == 0) && (ldc % 8 == 0) && !((uintptr_t)C_dev & 15) && !((uintptr_t)bias_dev & 15) &&
                       !((uintptr_t)aux_dev & 15);
-    KernelTimer timer(TK_GEMM0 + epilogue, 2.0 * M * N * K, stream);
+    KernelTimer timer(TK_GEMM0 + (epilogue == EPI_GELU_BOTH ? SGCLIP_EPI_BIAS_GELU_BF16 : epilogue == EPI_MULGRAD ? SGCLIP_EPI_BIAS_BF16 : epilogue),
+                      2.0 * M * N * K, stream);
     switch (epilogue) {
         case SGCLIP_EPI_BIAS_BF16: launch<SGCLIP_EPI_BIAS_BF16>(g, stream); break;
         case SGCLIP_EPI_BIAS_GELU_BF16: launch<SGCLIP_EPI_BIAS_GELU_BF16>(g, stream); break;
         case SGCLIP_EPI_BIAS_RESID_F32: launch<SGCLIP_EPI_BIAS_RESID_F32>(g, stream); break;
+        case EPI_GELU_BOTH: launch<EPI_GELU_BOTH>(g, stream); break;
+        case EPI_MULGRAD: launch<EPI_MULGRAD>(g, stream); break;
         case SGCLIP_EPI_PATCH_F32: launch<SGCLIP_EPI_PATCH_F32>(g, stream); break;
         case SGCLIP_EPI_F32: launch<SGCLIP_EPI_F32>(g, stream); break;
         case SGCLIP_EPI_F32_ATOMIC: {

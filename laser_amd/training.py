@@ -109,31 +109,40 @@ class TrainTower:
         qkv = torch.empty((M, 3 * d), dtype=BF16, device=x.device)
         ops.gemm_bf16(h1, w[f"{i}.qkv"], qkv, _lib.EPI_BIAS_BF16, bias=w[f"{i}.qkv_b"])
         a = ops.attention(qkv, n_seq, T, self.heads, causal, km)
-        x_mid = x.clone()
-        ops.gemm_bf16(a, w[f"{i}.o"], x_mid, _lib.EPI_BIAS_RESID_F32, bias=self._p(f"{b}.self_attn.out_proj.bias"))
+        # residual adds read the old stream from `aux` and write the new one: no copy of x
+        x_mid = torch.empty_like(x)
+        ops.gemm_bf16(a, w[f"{i}.o"], x_mid, _lib.EPI_BIAS_RESID_F32, bias=self._p(f"{b}.self_attn.out_proj.bias"), aux=x)
         h2 = ops.layernorm(x_mid, self._p(f"{b}.layer_norm2.weight"), self._p(f"{b}.layer_norm2.bias"), self.eps)
+        # fc1 leaves both the pre-activation u (kept for backward) and quick_gelu(u) (fc2's input) in one pass
         u = torch.empty((M, self.ffn), dtype=BF16, device=x.device)
-        ops.gemm_bf16(h2, w[f"{i}.fc1"], u, _lib.EPI_BIAS_BF16, bias=self._p(f"{b}.mlp.fc1.bias"))
-        g = G.quick_gelu(u)
-        x_out = x_mid.clone()
-        ops.gemm_bf16(g, w[f"{i}.fc2"], x_out, _lib.EPI_BIAS_RESID_F32, bias=self._p(f"{b}.mlp.fc2.bias"))
-        return x_out, (x, qkv, a, x_mid, u)
+        g = torch.empty((M, self.ffn), dtype=BF16, device=x.device)
+        ops.gemm_bf16(h2, w[f"{i}.fc1"], u, _lib.EPI_BIAS_GELU_BOTH_BF16, bias=self._p(f"{b}.mlp.fc1.bias"), aux=g)
+        x_out = torch.empty_like(x)
+        ops.gemm_bf16(g, w[f"{i}.fc2"], x_out, _lib.EPI_BIAS_RESID_F32, bias=self._p(f"{b}.mlp.fc2.bias"), aux=x_mid)
+        # with chunked recompute the saved set lives for one chunk's backward only, so the cheap-to-recompute tensors
+        # (LayerNorm outputs, the activation) are kept as well; without it they are rebuilt in backward to save memory
+        extra = (h1, h2, g) if self.recompute_chunk else None
+        return x_out, (x, qkv, a, x_mid, u, extra)
 
     def _layer_backward(self, i, saved, dx, n_seq, T, causal, km, sink: "GradSink"):
         """dx: f32 [M, d] gradient of the layer's output, overwritten with that of its input.
         Parameter gradients are ADDED to the sink's tensors."""
         b, w, d = f"{self.pre}.encoder.layers.{i}", self._w, self.d
-        x, qkv, a, x_mid, u = saved
+        x, qkv, a, x_mid, u, extra = saved
         zb = self._zero_bias
+        h1, h2, g = extra if extra is not None else (None, None, None)
         # MLP
         dxb = G.cast_bf16(dx)
-        g = G.quick_gelu(u)
+        if g is None:
+            g = G.quick_gelu(u)
         G.linear_wgrad(dxb, g, sink.get(f"{b}.mlp.fc2.weight"))
         G.colsum(dx, sink.get(f"{b}.mlp.fc2.bias"))
-        dg = G.linear_dgrad(dxb, w[f"{i}.fc2_t"], zb)
-        du = G.quick_gelu_bwd(u, dg)
-        del g, dg
-        h2 = ops.layernorm(x_mid, self._p(f"{b}.layer_norm2.weight"), self._p(f"{b}.layer_norm2.bias"), self.eps)
+        # du = (dx W2) * quick_gelu'(u): the activation's adjoint rides in the data-gradient GEMM's epilogue
+        du = torch.empty_like(u)
+        ops.gemm_bf16(dxb, w[f"{i}.fc2_t"], du, _lib.EPI_BIAS_MULGELUGRAD_BF16, bias=zb, aux=u)
+        del g
+        if h2 is None:
+            h2 = ops.layernorm(x_mid, self._p(f"{b}.layer_norm2.weight"), self._p(f"{b}.layer_norm2.bias"), self.eps)
         G.linear_wgrad(du, h2, sink.get(f"{b}.mlp.fc1.weight"))
         G.colsum(du, sink.get(f"{b}.mlp.fc1.bias"))
         dh2 = G.linear_dgrad(du, w[f"{i}.fc1_t"], zb)
@@ -146,7 +155,8 @@ class TrainTower:
         G.colsum(dx, sink.get(f"{b}.self_attn.out_proj.bias"))
         da = G.linear_dgrad(dxb, w[f"{i}.o_t"], zb)
         dqkv = G.attention_bwd(qkv, da, n_seq, T, self.heads, causal, km)
-        h1 = ops.layernorm(x, self._p(f"{b}.layer_norm1.weight"), self._p(f"{b}.layer_norm1.bias"), self.eps)
+        if h1 is None:
+            h1 = ops.layernorm(x, self._p(f"{b}.layer_norm1.weight"), self._p(f"{b}.layer_norm1.bias"), self.eps)
         wq, bq = sink.qkv(b, d)
         G.linear_wgrad(dqkv, h1, wq)
         G.colsum(dqkv, bq)
