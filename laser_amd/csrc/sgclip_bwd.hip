@@ -144,73 +144,95 @@ __global__ void cast_f32_bf16_kernel(const float *__restrict__ in, bf16_t *__res
 // ---------------------------------------------------------------------------
 constexpr int LN_RPW_MAX = 16;  // rows per wave: fewer when the launch would not fill the chip
 
-template <int NV, bool DY_BF16>
+// NV4 = float4 groups per lane: lane l holds columns 4 (l + 64 j) .. + 3, j < NV4 (d <= 256 NV4, d % 4 == 0)
+template <int NV4, bool DY_BF16>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ x, long long x_stride, int rows, int d,
                                                             const float *__restrict__ w, float eps, const void *dy_,
                                                             float *dx, int accumulate, float *__restrict__ dw,
                                                             float *__restrict__ db, int rpw) {
-    __shared__ float red[4][2][NV * 64];
+    __shared__ float red[4][2][NV4 * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float wv[NV], dwacc[NV], dbacc[NV];
+    const int nvec = d >> 2;
+    float4 wv[NV4], dwacc[NV4], dbacc[NV4];
 #pragma unroll
-    for (int j = 0; j < NV; j++) {
-        const int c = lane + 64 * j;
-        wv[j] = c < d ? w[c] : 0.f;
-        dwacc[j] = 0.f;
-        dbacc[j] = 0.f;
+    for (int j = 0; j < NV4; j++) {
+        const int v = lane + 64 * j;
+        wv[j] = v < nvec ? ((const float4 *)w)[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+        dwacc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dbacc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int row0 = (blockIdx.x * 4 + wave) * rpw;
     const float inv_d = 1.0f / d;
     for (int r = 0; r < rpw; r++) {
         const int row = row0 + r;
         if (row >= rows) break;
-        const float *xr = x + (size_t)row * x_stride;
-        float xv[NV], dyv[NV];
+        const float4 *xr = (const float4 *)(x + (size_t)row * x_stride);
+        float4 xv[NV4], dyv[NV4];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const int c = lane + 64 * j;
-            xv[j] = c < d ? xr[c] : 0.f;
-            if (DY_BF16)
-                dyv[j] = c < d ? (float)((const bf16_t *)dy_)[(size_t)row * d + c] : 0.f;
-            else
-                dyv[j] = c < d ? ((const float *)dy_)[(size_t)row * d + c] : 0.f;
-            s += xv[j];
+        for (int j = 0; j < NV4; j++) {
+            const int v = lane + 64 * j;
+            xv[j] = dyv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < nvec) {
+                xv[j] = xr[v];
+                if (DY_BF16) {
+                    const bf16x4 t = ((const bf16x4 *)((const bf16_t *)dy_ + (size_t)row * d))[v];
+                    dyv[j] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+                } else {
+                    dyv[j] = ((const float4 *)((const float *)dy_ + (size_t)row * d))[v];
+                }
+            }
+            s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
         }
         const float mean = wave_sum(s) * inv_d;
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const float a = (lane + 64 * j) < d ? xv[j] - mean : 0.f;
-            q += a * a;
+        for (int j = 0; j < NV4; j++) {
+            if (lane + 64 * j < nvec) {
+                const float a0 = xv[j].x - mean, a1 = xv[j].y - mean, a2 = xv[j].z - mean, a3 = xv[j].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
         }
         const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const float xh = (lane + 64 * j) < d ? (xv[j] - mean) * rstd : 0.f;
+        for (int j = 0; j < NV4; j++) {
+            const bool ok = lane + 64 * j < nvec;
+            float4 xh;
+            xh.x = ok ? (xv[j].x - mean) * rstd : 0.f;
+            xh.y = ok ? (xv[j].y - mean) * rstd : 0.f;
+            xh.z = ok ? (xv[j].z - mean) * rstd : 0.f;
+            xh.w = ok ? (xv[j].w - mean) * rstd : 0.f;
             xv[j] = xh;
-            const float g = dyv[j] * wv[j];
-            sg += g;
-            sgx += g * xh;
-            dwacc[j] += dyv[j] * xh;
-            dbacc[j] += dyv[j];
+            const float g0 = dyv[j].x * wv[j].x, g1 = dyv[j].y * wv[j].y, g2 = dyv[j].z * wv[j].z, g3 = dyv[j].w * wv[j].w;
+            sg += (g0 + g1) + (g2 + g3);
+            sgx += (g0 * xh.x + g1 * xh.y) + (g2 * xh.z + g3 * xh.w);
+            dwacc[j].x += dyv[j].x * xh.x; dwacc[j].y += dyv[j].y * xh.y; dwacc[j].z += dyv[j].z * xh.z; dwacc[j].w += dyv[j].w * xh.w;
+            dbacc[j].x += dyv[j].x; dbacc[j].y += dyv[j].y; dbacc[j].z += dyv[j].z; dbacc[j].w += dyv[j].w;
         }
         const float mg = wave_sum(sg) * inv_d, mgx = wave_sum(sgx) * inv_d;
-        float *dxr = dx + (size_t)row * d;
+        float4 *dxr = (float4 *)(dx + (size_t)row * d);
 #pragma unroll
-        for (int j = 0; j < NV; j++) {
-            const int c = lane + 64 * j;
-            if (c < d) {
-                const float v = rstd * (dyv[j] * wv[j] - mg - xv[j] * mgx);
-                dxr[c] = accumulate ? dxr[c] + v : v;
+        for (int j = 0; j < NV4; j++) {
+            const int v = lane + 64 * j;
+            if (v < nvec) {
+                float4 o;
+                o.x = rstd * (dyv[j].x * wv[j].x - mg - xv[j].x * mgx);
+                o.y = rstd * (dyv[j].y * wv[j].y - mg - xv[j].y * mgx);
+                o.z = rstd * (dyv[j].z * wv[j].z - mg - xv[j].z * mgx);
+                o.w = rstd * (dyv[j].w * wv[j].w - mg - xv[j].w * mgx);
+                if (accumulate) {
+                    const float4 c = dxr[v];
+                    o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
+                }
+                dxr[v] = o;
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < NV; j++) {
-        red[wave][0][lane + 64 * j] = dwacc[j];
-        red[wave][1][lane + 64 * j] = dbacc[j];
+    for (int j = 0; j < NV4; j++) {
+        ((float4 *)red[wave][0])[lane + 64 * j] = dwacc[j];
+        ((float4 *)red[wave][1])[lane + 64 * j] = dbacc[j];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += 256) {
@@ -993,8 +1015,9 @@ extern "C" int sgclip_layernorm_bwd(const float *x_dev, int64_t x_stride, int ro
     if (rows == 0) return SGCLIP_OK;
     BWD_ARGS_OK(x_dev && w_dev && dy_dev && dx_dev && dw_dev && db_dev && rows > 0 && d > 0 && x_stride >= d,
                 "sgclip_layernorm_bwd");
-    if (d > 1024) {
-        set_error("sgclip_layernorm_bwd: d=%d > 1024 is not supported", d);
+    if (d > 1024 || (d & 3) || (x_stride & 3) || ((uintptr_t)x_dev & 15) || ((uintptr_t)dx_dev & 15) || ((uintptr_t)w_dev & 15) ||
+        ((uintptr_t)dy_dev & 15)) {
+        set_error("sgclip_layernorm_bwd: d=%d must be a multiple of 4, <= 1024, rows 16-byte aligned", d);
         return SGCLIP_EINVAL;
     }
     const int rpw = std::max(1, std::min(LN_RPW_MAX, rows / (4 * 2048)));
@@ -1011,14 +1034,14 @@ extern "C" int sgclip_layernorm_bwd(const float *x_dev, int64_t x_stride, int ro
                                (long long)x_stride, rows, d, w_dev, eps, dy_dev, dx_dev, accumulate_dx, dw_dev, db_dev,   \
                                rpw);                                                                                       \
     } while (0)
-    if (d <= 128)
-        LN_BWD_LAUNCH(2);
+    if (d <= 256)
+        LN_BWD_LAUNCH(1);
     else if (d <= 512)
-        LN_BWD_LAUNCH(8);
+        LN_BWD_LAUNCH(2);
     else if (d <= 768)
-        LN_BWD_LAUNCH(12);
+        LN_BWD_LAUNCH(3);
     else
-        LN_BWD_LAUNCH(16);
+        LN_BWD_LAUNCH(4);
 #undef LN_BWD_LAUNCH
     return launch_check("sgclip_layernorm_bwd");
 }
