@@ -279,11 +279,6 @@ int sgclip_qkv_attention(const void *x_dev, int ldx, const void *w_qkv_dev, int 
  * that add atomically, so repeated calls accumulate (the caller zeroes C once). */
 int sgclip_gemm_tn_bf16(const void *A_dev, int lda, const void *B_dev, int ldb, float *C_dev, int ldc, int M, int N,
                         int Kd, void *stream);
-/* The same product plus colsum_a[m] += sum_k A[k][m] (f32 [M], accumulated like C): with A = dY the bias gradient of
- * the linear layer, taken from the operand tiles already staged for the weight gradient (one extra MFMA per A
- * fragment in the first column tile) instead of a separate pass over dY. */
-int sgclip_gemm_tn_bias_bf16(const void *A_dev, int lda, const void *B_dev, int ldb, float *C_dev, int ldc, int M, int N,
-                             int Kd, float *colsum_a_dev, void *stream);
 /* out[c][r] = in[r][c], bf16; in [rows, cols] (ld_in), out [cols, ld_out], ld_out >= rows,
  * columns rows..ld_out-1 zero-filled (pads the reduction dimension of a weight gradient). */
 int sgclip_transpose_bf16(const void *in_dev, int64_t ld_in, int rows, int cols, void *out_dev, int64_t ld_out,

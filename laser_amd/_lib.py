@@ -81,8 +81,6 @@ SIGNATURES = {
     "sgclip_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sgclip_gemm_tn_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p]),
-    "sgclip_gemm_tn_bias_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                           C.c_void_p, C.c_void_p]),
     "sgclip_qkv_attention_supported": (C.c_int, [C.c_int, C.c_int]),
     "sgclip_qkv_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                        C.c_int, C.c_void_p]),

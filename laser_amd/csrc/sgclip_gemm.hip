@@ -808,11 +808,10 @@ static __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0
 __device__ __forceinline__ int tn_swz(int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); }
 
 template <bool SYNC, bool DMA, bool READ>
-__device__ __forceinline__ void tn_substep(f32x4 (&acc)[4][8], f32x4 (&accb)[4], bool do_bias, const bf16x8 (&ca)[4],
-                                           const bf16x8 (&cb)[8], bf16x8 (&na)[4], bf16x8 (&nb)[8], const unsigned char *rd_row,
-                                           int a_x, int b_x, unsigned char *wr_slot, const unsigned (&goff)[8],
-                                           const unsigned char *abase, const unsigned char *bbase, const unsigned char *zero,
-                                           unsigned row_lim, int wave) {
+__device__ __forceinline__ void tn_substep(f32x4 (&acc)[4][8], const bf16x8 (&ca)[4], const bf16x8 (&cb)[8],
+                                           bf16x8 (&na)[4], bf16x8 (&nb)[8], const unsigned char *rd_row, int a_x, int b_x,
+                                           unsigned char *wr_slot, const unsigned (&goff)[8], const unsigned char *abase,
+                                           const unsigned char *bbase, const unsigned char *zero, unsigned row_lim, int wave) {
     if (SYNC) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -851,12 +850,6 @@ __device__ __forceinline__ void tn_substep(f32x4 (&acc)[4][8], f32x4 (&accb)[4],
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
-    if (do_bias) {   // column sums of A (the bias gradient): A^T times a block of ones, every output column the same
-        const bf16_t one = (bf16_t)1.0f;
-        const bf16x8 ones = {one, one, one, one, one, one, one, one};
-#pragma unroll
-        for (int i = 0; i < 4; i++) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], ones, accb[i], 0, 0, 0);
-    }
     if (DMA) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -891,11 +884,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[2][4], fb[2][8];
-    // bias gradient = column sums of A: taken once per row tile, by the waves of column tile 0 that hold columns 0..127
-    f32x4 accb[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = g.aux != nullptr && tn == 0 && wn == 0;
 
     // DMA piece p (32 per operand and stage) = stage rows 2p, 2p + 1; lane -> row 2p + (lane >> 5), LDS chunk position
     // lane & 31, which holds source chunk (lane & 31) ^ swz(row).  q < 4: A pieces wave + 8 q; q >= 4: B pieces.
@@ -960,32 +948,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmArgs g) {
     for (; s < ns - 2; s++) {
         unsigned char *cur = lds + (s & 1) * P64_SLOT, *nxt = lds + ((s + 1) & 1) * P64_SLOT;
         const unsigned lim = (unsigned)max(0, min(64, k_len - 64 * (s + 2)));
-        tn_substep<false, false, true>(acc, accb, do_bias, fa[0], fb[0], fa[1], fb[1], cur + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
+        tn_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
                                        zero, lim, wave);
-        tn_substep<true, true, true>(acc, accb, do_bias, fa[1], fb[1], fa[0], fb[0], nxt + row_off, a_x, b_x, cur, goff, abase, bbase, zero, lim,
+        tn_substep<true, true, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + row_off, a_x, b_x, cur, goff, abase, bbase, zero, lim,
                                      wave);
         abase += astep;
         bbase += bstep;
     }
     {
         unsigned char *cur = lds + (s & 1) * P64_SLOT, *nxt = lds + ((s + 1) & 1) * P64_SLOT;
-        tn_substep<false, false, true>(acc, accb, do_bias, fa[0], fb[0], fa[1], fb[1], cur + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
+        tn_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
                                        zero, 0u, wave);
-        tn_substep<true, false, true>(acc, accb, do_bias, fa[1], fb[1], fa[0], fb[0], nxt + row_off, a_x, b_x, cur, goff, abase, bbase, zero, 0u,
+        tn_substep<true, false, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + row_off, a_x, b_x, cur, goff, abase, bbase, zero, 0u,
                                       wave);
-        tn_substep<false, false, true>(acc, accb, do_bias, fa[0], fb[0], fa[1], fb[1], nxt + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
+        tn_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], nxt + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
                                        zero, 0u, wave);
-        tn_substep<false, false, false>(acc, accb, do_bias, fa[1], fb[1], fa[0], fb[0], nxt, a_x, b_x, cur, goff, abase, bbase, zero, 0u, wave);
-    }
-    if (do_bias && (lane & 15) == 0) {
-        // accb[i][e] = sum over this workgroup's reduction rows of A[.][m0 + wm*64 + i*16 + (lane >> 4)*4 + e]
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + e;
-                if (m < g.M) unsafeAtomicAdd((float *)g.aux + m, accb[i][e]);
-            }
+        tn_substep<false, false, false>(acc, fa[1], fb[1], fa[0], fb[0], nxt, a_x, b_x, cur, goff, abase, bbase, zero, 0u, wave);
     }
     __syncthreads();
     epilogue_passes<SGCLIP_EPI_F32_ATOMIC, 4, 8>(g, acc, (float *)(lds + wave * epi_pass_bytes(8)), m0 + wm * 64, n0 + wn * 128,
@@ -1163,11 +1141,6 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
 
 extern "C" int sgclip_gemm_tn_bf16(const void *A_dev, int lda, const void *B_dev, int ldb, float *C_dev, int ldc, int M, int N,
                                    int Kd, void *stream_) {
-    return sgclip_gemm_tn_bias_bf16(A_dev, lda, B_dev, ldb, C_dev, ldc, M, N, Kd, nullptr, stream_);
-}
-
-extern "C" int sgclip_gemm_tn_bias_bf16(const void *A_dev, int lda, const void *B_dev, int ldb, float *C_dev, int ldc, int M,
-                                        int N, int Kd, float *colsum_a_dev, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (M == 0 || N == 0 || Kd == 0) return SGCLIP_OK;
     if (!A_dev || !B_dev || !C_dev || M < 0 || N < 0 || Kd < 0 || (M & 7) || (N & 7) || lda < M || ldb < N || ldc < N) {
@@ -1185,7 +1158,6 @@ extern "C" int sgclip_gemm_tn_bias_bf16(const void *A_dev, int lda, const void *
     g.A = (const bf16_t *)A_dev;
     g.W = (const bf16_t *)B_dev;
     g.C = C_dev;
-    g.aux = colsum_a_dev;   // f32 [M], accumulated; null = none
     g.lda = lda;
     g.ldw = ldb;
     g.ldc = ldc;

@@ -193,11 +193,10 @@ def linear_dgrad(dy: torch.Tensor, w_t: torch.Tensor, zero_bias: torch.Tensor) -
     return gemm_bf16(dy, w_t, dx, _lib.EPI_BIAS_BF16, bias=zero_bias)
 
 
-def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None,
-                 bias_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out f32 [out, in] += dy^T x for dy bf16 [M, out], x bf16 [M, in] (out: zeros when omitted); M is zero-padded
     to a multiple of 64.  The reduction over M (all tokens of the batch) is split over workgroups that add into
-    `out` atomically, so repeated calls accumulate.  bias_grad f32 [out]: += column sums of dy, from the same pass."""
+    `out` atomically, so repeated calls accumulate."""
     M = dy.shape[0]
     if out is None:
         out = torch.zeros((dy.shape[1], x.shape[1]), dtype=F32, device=dy.device)
@@ -205,11 +204,9 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] 
     if _TN_WGRAD and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and dy.stride(1) == 1 and x.stride(1) == 1 \
             and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
         # both operands as they lie in memory (rows = the reduction index); fragments are transposed on the LDS read
-        _lib.check(_lib.load().sgclip_gemm_tn_bias_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
-                                                        out.stride(0), dy.shape[1], x.shape[1], M, _ptr(bias_grad), _stream()))
+        _lib.check(_lib.load().sgclip_gemm_tn_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
+                                                   out.stride(0), dy.shape[1], x.shape[1], M, _stream()))
         return out
-    if bias_grad is not None:
-        colsum(dy, bias_grad)
     Mp = pad64(M)
     dyt = transpose_bf16(dy, Mp)
     xt = transpose_bf16(x, Mp)

@@ -98,15 +98,6 @@ def test_gemm_tn_accumulates_a_transposed_product(dev, Kd, M, N):
     torch.cuda.synchronize()
     want = c0.double() + a.double().t() @ b.double()
     assert ((c.double() - want).abs().max() / want.abs().max()).item() <= 2e-5
-    # the same product with the column sums of A (a bias gradient) from the same pass, accumulated onto s0
-    s0 = _randn((M,), dev, 64, 1.0)
-    sums, c2 = s0.clone(), c0.clone()
-    _lib.check(_lib.load().sgclip_gemm_tn_bias_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c2.data_ptr(),
-                                                    c2.stride(0), M, N, Kd, sums.data_ptr(), _stream()))
-    torch.cuda.synchronize()
-    assert ((c2.double() - want).abs().max() / want.abs().max()).item() <= 2e-5
-    swant = s0.double() + a.double().sum(dim=0)
-    assert ((sums.double() - swant).abs().max() / swant.abs().max()).item() <= 2e-5
 
 
 def test_gemm_tn_exact_small_integers(dev):
@@ -127,12 +118,8 @@ def test_linear_wgrad(dev, M, out_f, in_f):
     dy = _randn((M, out_f), dev, 53, 1.0, torch.bfloat16)
     x = _randn((M, in_f), dev, 54, 1.0, torch.bfloat16)
     dw = G.linear_wgrad(dy, x)
-    db = torch.zeros(out_f, device=dev)
-    dw2 = G.linear_wgrad(dy, x, bias_grad=db)
     torch.cuda.synchronize()
     assert _rel(dw, dy.float().t() @ x.float()) <= 1e-3
-    assert _rel(dw2, dy.float().t() @ x.float()) <= 1e-3
-    assert _rel(db, dy.float().sum(dim=0)) <= 1e-3
 
 
 def test_cast(dev):
