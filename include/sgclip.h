@@ -237,6 +237,10 @@ int sgclip_mask_unpack(const uint8_t *packed_dev, size_t packed_bytes, const sgc
 int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, int ldw, void *C_dev, int ldc, int M, int N,
                      int K, int epilogue, const float *bias_dev, const void *aux_dev, int aux_rows,
                      void *stream);
+/* sgclip_gemm_bf16 with SGCLIP_EPI_BIAS_MULGELUGRAD_BF16 (u_dev = its aux) that also accumulates colsum[n] += sum_m C[m][n]
+ * (f32 [N], caller zeroes; NULL = none): C is the gradient at fc1's output, its column sums fc1's bias gradient. */
+int sgclip_gemm_mulgelugrad_bf16(const void *A_dev, int lda, const void *W_dev, int ldw, void *C_dev, int ldc, int M, int N, int K,
+                                 const float *bias_dev, const void *u_dev, float *colsum_dev, void *stream);
 /* y[rows, out] = x[rows, in] * w[out, in]^T for fp32 operands, each split into bf16
  * hi + lo halves on the MFMA (three products), error ~2^-16 relative; in % 16 == 0. */
 int sgclip_linear_f32(const float *x_dev, const float *w_dev, int rows, int out_features, int in_features,
@@ -289,6 +293,9 @@ int sgclip_colsum(const void *in_dev, int in_dtype, int64_t ld, int M, int N, fl
 int sgclip_quick_gelu(const void *u_dev, void *g_dev, int64_t n, void *stream);
 int sgclip_quick_gelu_bwd(const void *u_dev, const void *dg_dev, void *du_dev, int64_t n, void *stream);
 int sgclip_cast_f32_bf16(const float *in_dev, void *out_dev, int64_t n, void *stream);
+/* out bf16 [M, N] = in f32 [M, N] and colsum[n] += sum_m in[m][n] in one pass (a gradient cast for the bf16 products
+ * that is also a bias gradient); contiguous rows, N % 8 == 0, N <= 2048; the caller zeroes colsum. */
+int sgclip_cast_colsum_f32_bf16(const float *in_dev, void *out_dev, int M, int N, float *colsum_dev, void *stream);
 /* LayerNorm adjoint.  x f32 [rows, d] (row stride x_stride), dy bf16 or f32 [rows, d];
  * dx f32 [rows, d] (accumulate_dx: added to what dx holds); dw, db f32 [d], accumulated (caller zeroes). */
 int sgclip_layernorm_bwd(const float *x_dev, int64_t x_stride, int rows, int d, const float *w_dev, float eps,

@@ -91,6 +91,9 @@ SIGNATURES = {
     "sgclip_quick_gelu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "sgclip_quick_gelu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "sgclip_cast_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "sgclip_cast_colsum_f32_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "sgclip_gemm_mulgelugrad_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgclip_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgclip_attention_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -113,6 +113,53 @@ __global__ void quick_gelu_bwd_kernel(const bf16_t *__restrict__ u, const bf16_t
     }
 }
 
+// out = bf16(in) and colsum[n] += sum_m in[m][n] in one pass over in f32 [M, N] (contiguous rows, N % 8 == 0,
+// N / 8 <= 256): the cast of a gradient for the bf16 GEMMs and the bias gradient it also is.  Thread = 8 columns,
+// a block's blockDim.x / (N / 8) row lanes walk its slice of rows.
+__global__ __launch_bounds__(256) void cast_colsum_kernel(const float *__restrict__ in, bf16_t *__restrict__ out, int M, int N,
+                                                          float *__restrict__ colsum, int rows_per_block) {
+    __shared__ float red[256][9];
+    const int ct = N >> 3, rt = blockDim.x / ct;
+    const int tx = threadIdx.x % ct, ty = threadIdx.x / ct;
+    const int m0 = blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ty < rt) {
+        auto one = [&](int m, const float4 &a, const float4 &b) {
+            bf16x8 y;
+            y[0] = (bf16_t)a.x; y[1] = (bf16_t)a.y; y[2] = (bf16_t)a.z; y[3] = (bf16_t)a.w;
+            y[4] = (bf16_t)b.x; y[5] = (bf16_t)b.y; y[6] = (bf16_t)b.z; y[7] = (bf16_t)b.w;
+            *(bf16x8 *)(out + (size_t)m * N + tx * 8) = y;
+            s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+            s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
+        };
+        int m = m0 + ty;
+        for (; m + 3 * rt < m1; m += 4 * rt) {   // four rows in flight per thread
+            float4 a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float *p = in + (size_t)(m + r * rt) * N + tx * 8;
+                a[r] = *(const float4 *)p;
+                b[r] = *(const float4 *)(p + 4);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) one(m + r * rt, a[r], b[r]);
+        }
+        for (; m < m1; m += rt) {
+            const float *p = in + (size_t)m * N + tx * 8;
+            one(m, *(const float4 *)p, *(const float4 *)(p + 4));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) red[threadIdx.x][q] = s[q];
+    __syncthreads();
+    // one dword per lane, neighbouring lanes on neighbouring columns: a wave's atomic instruction covers whole cache lines
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+        float t = 0.f;
+        for (int y = 0; y < rt; y++) t += red[y * ct + (c >> 3)][c & 7];
+        atomicAdd(colsum + c, t);
+    }
+}
+
 // out += <a, b>
 __global__ __launch_bounds__(256) void dot_f32_kernel(const float *__restrict__ a, const float *__restrict__ b, long long n,
                                                       float *__restrict__ out) {
@@ -1007,6 +1054,17 @@ extern "C" int sgclip_cast_f32_bf16(const float *in_dev, void *out_dev, int64_t 
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, in_dev,
                        (bf16_t *)out_dev, (long long)n);
     return launch_check("sgclip_cast_f32_bf16");
+}
+
+extern "C" int sgclip_cast_colsum_f32_bf16(const float *in_dev, void *out_dev, int M, int N, float *colsum_dev, void *stream) {
+    if (M == 0 || N == 0) return SGCLIP_OK;
+    BWD_ARGS_OK(in_dev && out_dev && colsum_dev && M > 0 && N > 0 && N % 8 == 0 && N / 8 <= 256 && !((uintptr_t)in_dev & 15) &&
+                    !((uintptr_t)out_dev & 15),
+                "sgclip_cast_colsum_f32_bf16 (N a multiple of 8, at most 2048; 16-byte alignment)");
+    const int rpb = std::max(16, ceil_div(M, 1024));   // every block ends in N atomics on the same addresses
+    hipLaunchKernelGGL(cast_colsum_kernel, dim3(ceil_div(M, rpb)), dim3(256), 0, (hipStream_t)stream, in_dev, (bf16_t *)out_dev,
+                       M, N, colsum_dev, rpb);
+    return launch_check("sgclip_cast_colsum_f32_bf16");
 }
 
 extern "C" int sgclip_layernorm_bwd(const float *x_dev, int64_t x_stride, int rows, int d, const float *w_dev, float eps,

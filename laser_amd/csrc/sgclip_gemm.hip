@@ -43,6 +43,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int wide_epilogue;  // N % 8 == 0, ldc % 8 == 0 and C, bias, aux 16-byte aligned
     int debug_mode;     // diagnostics only: 1 = skip epilogue stores, 2 = single K step
+    float *colsum;      // EPI_MULGRAD through epilogue_passes: += column sums of C (null: none)
 };
 
 // one 1 KiB piece (8 rows x 128 B) of an operand tile: lane -> (row, swizzled chunk)
@@ -422,6 +423,9 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
             bias[q] = b.x; bias[q + 1] = b.y; bias[q + 2] = b.z; bias[q + 3] = b.w;
         }
     }
+    float csum[EPI == EPI_MULGRAD ? CPL : 1];   // this lane's columns summed over the rows it stores
+#pragma unroll
+    for (int q = 0; q < (EPI == EPI_MULGRAD ? CPL : 1); q++) csum[q] = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; i++) {
 #pragma unroll
@@ -447,7 +451,10 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
                 if constexpr (EPI == EPI_MULGRAD) {
                     const bf16x8 u = *(const bf16x8 *)((const bf16_t *)g.aux + (size_t)m * g.ldc + n);
 #pragma unroll
-                    for (int q = 0; q < 8; q++) o[q] = (bf16_t)(v[q] * quick_gelu_grad((float)u[q]));
+                    for (int q = 0; q < 8; q++) {
+                        o[q] = (bf16_t)(v[q] * quick_gelu_grad((float)u[q]));
+                        csum[q] += (float)o[q];
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 8; q++) o[q] = (bf16_t)(EPI == SGCLIP_EPI_BIAS_GELU_BF16 ? quick_gelu(v[q]) : v[q]);
@@ -476,6 +483,21 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
             }
         }
         wave_lds_sync();
+    }
+    if constexpr (EPI == EPI_MULGRAD) {
+        if (g.colsum) {
+            // the lanes of one column group are the RPI row lanes, LPR apart; the wave's NJ * 16 column sums are left at
+            // the start of its region for the kernel to add up over the waves of a column strip
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) csum[q] += __shfl_xor(csum[q], o, 64);
+            }
+            if (rl == 0) {
+#pragma unroll
+                for (int q = 0; q < CPL; q++) region[cl + q] = csum[q];
+            }
+        }
     }
 }
 
@@ -778,6 +800,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64_kernel(GemmArgs g) {
         // without its HBM traffic
         epilogue_passes<EPI, 4, 8>(g, acc, (float *)(lds + wave * epi_pass_bytes(8)), (g.debug_mode == 9 ? 0 : m0) + wm * 64,
                                    n0 + wn * 128, lane);
+        if constexpr (EPI == EPI_MULGRAD) {
+            if (g.colsum) {   // uniform over the grid
+                // one atomic per column of the tile, a wave's 64 on neighbouring addresses (atomics that share a cache
+                // line within one instruction cost one; scattered ones serialise)
+                __syncthreads();
+                if (tid < 256 && n0 + tid < g.N) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) t += ((const float *)(lds + (r * 2 + (tid >> 7)) * epi_pass_bytes(8)))[tid & 127];
+                    unsafeAtomicAdd(g.colsum + n0 + tid, t);
+                }
+            }
+        }
     } else {
 #pragma unroll
         for (int half = 0; half < 2; half++) {
@@ -989,6 +1024,23 @@ static int gemm_variant() {
     return v;
 }
 
+static int pipe64_min_tiles() {   // 256 x 256 tiles from this many on (smaller grids: 256 x 128 tiles, two workgroups per CU)
+    static int min_tiles = -1;
+    if (min_tiles < 0) {
+        const char *e = getenv("SGCLIP_PIPE64_MIN_TILES");
+        min_tiles = e ? atoi(e) : 256;
+    }
+    return min_tiles;
+}
+
+// whether launch() runs the shape on gemm_pipe64_kernel (k_shortest: the shortest K slice of a split launch)
+static bool runs_on_pipe64(int M, int N, int K, int k_shortest, int splits) {
+    const long big_tiles = (long)ceil_div(M, 256) * ceil_div(N, 256) * splits;
+    return gemm_variant() >= 7 && big_tiles >= pipe64_min_tiles() && M > 128 && K % 64 == 0 && k_shortest >= 128 && N >= 256;
+}
+
+static thread_local float *g_mulgrad_colsum = nullptr;   // set around its call by sgclip_gemm_mulgelugrad_bf16
+
 template <int EPI>
 static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
     GemmArgs g = g0;
@@ -998,14 +1050,9 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
     const int variant = gemm_variant();
     const bool use32 = variant == 2 || (variant >= 3 && g.K <= 1024);
     const long big_tiles = (long)ceil_div(g.M, 256) * ceil_div(g.N, 256) * splits;
-    static int min_tiles = -1;   // 256 x 256 tiles from this many on (smaller grids: 256 x 128 tiles, two workgroups per CU)
-    if (min_tiles < 0) {
-        const char *e = getenv("SGCLIP_PIPE64_MIN_TILES");
-        min_tiles = e ? atoi(e) : 256;
-    }
     // the last K slice of a split launch is the shortest (split_k_setup): the 64-deep pipeline needs two stages of it
     const int k_shortest = g.k_total - (splits - 1) * g.K;
-    if (variant >= 7 && big_tiles >= min_tiles && g.M > 128 && g.K % 64 == 0 && k_shortest >= 128 && g.N >= 256) {
+    if (runs_on_pipe64(g.M, g.N, g.K, k_shortest, splits)) {
         g.tiles_m = ceil_div(g.M, 256);
         g.tiles_n = ceil_div(g.N, 256);
         auto go = [&](auto kernel) {
@@ -1093,6 +1140,7 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
     g.K = K;
     g.k_total = K;
     g.aux_rows = aux_rows;
+    g.colsum = epilogue == EPI_MULGRAD ? g_mulgrad_colsum : nullptr;
     g.tiles_m = 0;
     g.tiles_n = ceil_div(N, BN);
     {
@@ -1137,6 +1185,22 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
         default: set_error("sgclip_gemm_bf16: unknown epilogue %d", epilogue); return SGCLIP_EINVAL;
     }
     return launch_check("sgclip_gemm_bf16");
+}
+
+extern "C" int sgclip_gemm_mulgelugrad_bf16(const void *A_dev, int lda, const void *W_dev, int ldw, void *C_dev, int ldc, int M,
+                                            int N, int K, const float *bias_dev, const void *u_dev, float *colsum_dev,
+                                            void *stream) {
+    const bool wide = (N % 8 == 0) && (ldc % 8 == 0) && !((uintptr_t)C_dev & 15) && !((uintptr_t)bias_dev & 15) &&
+                      !((uintptr_t)u_dev & 15);
+    if (colsum_dev && M > 0 && N > 0 && !(wide && runs_on_pipe64(M, N, K, K, 1))) {
+        // shapes that the 256 x 256 kernel does not take: the product, then a pass over C
+        const int rc = sgclip_gemm_bf16(A_dev, lda, W_dev, ldw, C_dev, ldc, M, N, K, EPI_MULGRAD, bias_dev, u_dev, 0, stream);
+        return rc != SGCLIP_OK ? rc : sgclip_colsum(C_dev, SGCLIP_DTYPE_BF16, ldc, M, N, colsum_dev, stream);
+    }
+    g_mulgrad_colsum = colsum_dev;
+    const int rc = sgclip_gemm_bf16(A_dev, lda, W_dev, ldw, C_dev, ldc, M, N, K, EPI_MULGRAD, bias_dev, u_dev, 0, stream);
+    g_mulgrad_colsum = nullptr;
+    return rc;
 }
 
 extern "C" int sgclip_gemm_tn_bf16(const void *A_dev, int lda, const void *B_dev, int ldb, float *C_dev, int ldc, int M, int N,

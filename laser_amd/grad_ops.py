@@ -72,6 +72,36 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def cast_bf16_colsum(x: torch.Tensor, colsum_out: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of x (f32 [M, N]) with colsum_out (f32 [N]) += column sums of x, in one pass over x."""
+    assert x.dtype == F32 and x.dim() == 2 and x.is_contiguous()
+    M, N = x.shape
+    if N % 8 or N > 2048:
+        colsum(x, colsum_out)
+        return cast_bf16(x)
+    assert colsum_out.dtype == F32 and colsum_out.is_contiguous() and colsum_out.numel() == N
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _lib.check(_lib.load().sgclip_cast_colsum_f32_bf16(x.data_ptr(), y.data_ptr(), M, N, colsum_out.data_ptr(), _stream()))
+    return y
+
+
+def fc2_dgrad_through_gelu(dy: torch.Tensor, w_t: torch.Tensor, u: torch.Tensor, zero_bias: torch.Tensor,
+                           colsum_out: torch.Tensor) -> torch.Tensor:
+    """du = (dy w_t^T) * quick_gelu'(u) (bf16 [M, N]) with colsum_out (f32 [N]) += column sums of du: the gradient at
+    fc1's output and fc1's bias gradient from one GEMM (dy bf16 [M, K], w_t bf16 [N, K] = fc2's weight transposed)."""
+    assert dy.dtype == BF16 and w_t.dtype == BF16 and u.dtype == BF16 and u.is_contiguous()
+    assert dy.stride(1) == 1 and w_t.stride(1) == 1
+    M, K = dy.shape
+    N = w_t.shape[0]
+    assert w_t.shape[1] == K and u.shape == (M, N)
+    assert colsum_out.dtype == F32 and colsum_out.is_contiguous() and colsum_out.numel() == N and zero_bias.numel() >= N
+    du = torch.empty_like(u)
+    _lib.check(_lib.load().sgclip_gemm_mulgelugrad_bf16(dy.data_ptr(), dy.stride(0), w_t.data_ptr(), w_t.stride(0), du.data_ptr(),
+                                                        N, M, N, K, zero_bias.data_ptr(), u.data_ptr(), colsum_out.data_ptr(),
+                                                        _stream()))
+    return du
+
+
 def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor, dw: torch.Tensor, db: torch.Tensor,
                   dx: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """dx (f32 [rows, d]; added to `dx` when accumulate) and dw / db (+=) of y = LayerNorm(x) w + b."""

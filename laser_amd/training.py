@@ -132,27 +132,24 @@ class TrainTower:
         zb = self._zero_bias
         h1, h2, g = extra if extra is not None else (None, None, None)
         # MLP
-        dxb = G.cast_bf16(dx)
+        dxb = G.cast_bf16_colsum(dx, sink.get(f"{b}.mlp.fc2.bias"))   # the cast's pass over dx is the bias gradient too
         if g is None:
             g = G.quick_gelu(u)
         G.linear_wgrad(dxb, g, sink.get(f"{b}.mlp.fc2.weight"))
-        G.colsum(dx, sink.get(f"{b}.mlp.fc2.bias"))
-        # du = (dx W2) * quick_gelu'(u): the activation's adjoint rides in the data-gradient GEMM's epilogue
-        du = torch.empty_like(u)
-        ops.gemm_bf16(dxb, w[f"{i}.fc2_t"], du, _lib.EPI_BIAS_MULGELUGRAD_BF16, bias=zb, aux=u)
+        # du = (dx W2) * quick_gelu'(u): the activation's adjoint and fc1's bias gradient ride in the data-gradient
+        # GEMM's epilogue
+        du = G.fc2_dgrad_through_gelu(dxb, w[f"{i}.fc2_t"], u, zb, sink.get(f"{b}.mlp.fc1.bias"))
         del g
         if h2 is None:
             h2 = ops.layernorm(x_mid, self._p(f"{b}.layer_norm2.weight"), self._p(f"{b}.layer_norm2.bias"), self.eps)
         G.linear_wgrad(du, h2, sink.get(f"{b}.mlp.fc1.weight"))
-        G.colsum(du, sink.get(f"{b}.mlp.fc1.bias"))
         dh2 = G.linear_dgrad(du, w[f"{i}.fc1_t"], zb)
         G.layernorm_bwd(x_mid, self._p(f"{b}.layer_norm2.weight"), self.eps, dh2, sink.get(f"{b}.layer_norm2.weight"),
                         sink.get(f"{b}.layer_norm2.bias"), dx=dx, accumulate=True)
         del du, h2, dh2
         # attention
-        dxb = G.cast_bf16(dx)
+        dxb = G.cast_bf16_colsum(dx, sink.get(f"{b}.self_attn.out_proj.bias"))
         G.linear_wgrad(dxb, a, sink.get(f"{b}.self_attn.out_proj.weight"))
-        G.colsum(dx, sink.get(f"{b}.self_attn.out_proj.bias"))
         da = G.linear_dgrad(dxb, w[f"{i}.o_t"], zb)
         dqkv = G.attention_bwd(qkv, da, n_seq, T, self.heads, causal, km)
         if h1 is None:

@@ -127,6 +127,38 @@ def test_cast(dev):
     assert torch.equal(G.cast_bf16(x), x.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("M,N", [(1, 8), (50, 768), (40000, 768), (3001, 1024), (70, 2048), (33, 520), (9, 100)])
+def test_cast_with_column_sums_in_the_same_pass(dev, M, N):
+    x = _randn((M, N), dev, 6, 3.0)
+    acc = torch.full((N,), 0.5, dtype=torch.float32, device=dev)
+    y = G.cast_bf16_colsum(x, acc)
+    torch.cuda.synchronize()
+    assert torch.equal(y, x.to(torch.bfloat16))
+    ref = 0.5 + x.double().sum(0)
+    assert float((acc.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(x.abs().sum(0).max()))
+
+
+# (70000, 3072, 768) runs on the 256 x 256 kernel (column sums in its epilogue), the others on a pass over the result
+@pytest.mark.parametrize("M,N,K", [(70000, 3072, 768), (300, 512, 256), (65, 264, 64), (66000, 1032, 512)])
+def test_fc2_dgrad_through_gelu_with_fc1_bias_gradient(dev, M, N, K):
+    dy = _randn((M, K), dev, 7, 0.5).to(torch.bfloat16)
+    w_t = _randn((N, K), dev, 8, 0.05).to(torch.bfloat16)
+    u = _randn((M, N), dev, 9, 1.5).to(torch.bfloat16)
+    zb = torch.zeros(N, dtype=torch.float32, device=dev)
+    acc = torch.full((N,), -2.0, dtype=torch.float32, device=dev)
+    du = G.fc2_dgrad_through_gelu(dy, w_t, u, zb, acc)
+    plain = torch.empty_like(u)
+    ops.gemm_bf16(dy, w_t, plain, _lib.EPI_BIAS_MULGELUGRAD_BF16, bias=zb, aux=u)
+    torch.cuda.synchronize()
+    assert torch.equal(du, plain)
+    uf = u.float()
+    sig = torch.sigmoid(1.702 * uf)
+    ref = (dy.float() @ w_t.float().t()) * (sig * (1 + 1.702 * uf * (1 - sig)))
+    assert _rel(du.float(), ref) <= 1e-2
+    want = -2.0 + du.double().sum(0)
+    assert float((acc.double() - want).abs().max()) <= 2e-5 * max(1.0, float(du.float().abs().sum(0).max()))
+
+
 @pytest.mark.parametrize("rows,d", [(1, 128), (50, 768), (1030, 512), (7, 1024)])
 @pytest.mark.parametrize("dy_bf16", [False, True])
 def test_layernorm_bwd(dev, rows, d, dy_bf16):
