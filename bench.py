@@ -382,15 +382,16 @@ def train_sub_result(args, device, tok):
     g_fl = sum(kinds[k][2] for k in (0, 1, 2, 3, 4))
     w_ms, _, w_fl = kinds[5]
     out = {"workload": f"2 clips x {args.frames} frames x {args.objects} objects x {args.objects * (args.objects - 1)} ordered "
-                       f"pairs/frame at 1280x720, {args.model}, forward + backward + Adam, image towers recomputed in "
-                       f"chunks of 2048 crops during backward, binary cross-entropy stand-in loss",
+                       f"pairs/frame at 1280x720, {args.model}, forward + backward + Adam, image towers in chunks of 2048 crops "
+                       f"(a chunk's activations stay in HBM while it has room, else its forward is recomputed during "
+                       f"backward), binary cross-entropy stand-in loss",
            "ms_per_step": ms, "crops_per_s": n_crops / (ms * 1e-3), "crops": n_crops,
            "gemm_nt_ms": g_ms, "gemm_nt_tflops": g_fl / (g_ms * 1e-3) / 1e12 if g_ms else 0.0,
            "gemm_tn_weight_grad_ms": w_ms, "gemm_tn_weight_grad_tflops": w_fl / (w_ms * 1e-3) / 1e12 if w_ms else 0.0,
            "roofline_frac_mfma": (g_fl + w_fl) / ((g_ms + w_ms) * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if g_ms + w_ms else 0.0,
            "peak_mem_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
-           "note": "GEMM times from HIP events around every launch of one step (forward, recompute, data and weight "
-                   "gradients)"}
+           "note": "GEMM times from HIP events around every launch of one step (forward, any recompute, data and "
+                   "weight gradients)"}
     del model, flat, opt, di
     torch.cuda.empty_cache()
     return out

@@ -193,11 +193,14 @@ class PredicateModel(nn.Module):
             self.invalidate_packed_weights()
         return self._flat
 
-    def set_recompute_chunk(self, images: Optional[int]):
-        """Bound the activation memory of the train step: the image towers keep no activations and recompute
-        their forward, `images` crops at a time, during backward (None: keep everything, no recompute)."""
+    def set_recompute_chunk(self, images: Optional[int], keep_activations: bool = True):
+        """Bound the activation memory of the train step: the image towers run `images` crops at a time and recompute
+        a chunk's forward during backward (None: one pass, keep everything).  With keep_activations, chunks keep
+        their activations while the card has memory to spare and only the rest are recomputed."""
         for prefix in TOWER_PREFIXES:
-            self._trainers()[prefix][0].recompute_chunk = images
+            tower = self._trainers()[prefix][0]
+            tower.recompute_chunk = images
+            tower.keep_activations = keep_activations
 
     def _grad_mode(self) -> bool:
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())

@@ -70,6 +70,8 @@ class TrainTower:
         self.flat: Optional["FlatParameters"] = None   # set by FlatParameters.attach
         self.flat_prefix = ""
         self.recompute_chunk: Optional[int] = None      # images per recomputed chunk (None: keep all activations)
+        self.keep_activations = True    # chunked: keep the activations of as many chunks as free memory allows
+        self.save_extras = False        # also save what one elementwise pass rebuilds (LayerNorm outputs, activation)
 
     def param_list(self) -> List[nn.Parameter]:
         return [self.params[n] for n in self.names]
@@ -119,9 +121,9 @@ class TrainTower:
         ops.gemm_bf16(h2, w[f"{i}.fc1"], u, _lib.EPI_BIAS_GELU_BOTH_BF16, bias=self._p(f"{b}.mlp.fc1.bias"), aux=g)
         x_out = torch.empty_like(x)
         ops.gemm_bf16(g, w[f"{i}.fc2"], x_out, _lib.EPI_BIAS_RESID_F32, bias=self._p(f"{b}.mlp.fc2.bias"), aux=x_mid)
-        # with chunked recompute the saved set lives for one chunk's backward only, so the cheap-to-recompute tensors
-        # (LayerNorm outputs, the activation) are kept as well; without it they are rebuilt in backward to save memory
-        extra = (h1, h2, g) if self.recompute_chunk else None
+        # a recomputed chunk's saved set lives for that chunk's backward only, so the cheap-to-recompute tensors
+        # (LayerNorm outputs, the activation) are kept as well; otherwise they are rebuilt in backward to save memory
+        extra = (h1, h2, g) if self.save_extras else None
         return x_out, (x, qkv, a, x_mid, u, extra)
 
     def _layer_backward(self, i, saved, dx, n_seq, T, causal, km, sink: "GradSink"):
@@ -337,6 +339,12 @@ class FlatParameters:
             torch.autograd.graph.increment_version(p)
 
 
+def _headroom(dev) -> int:
+    """Bytes a torch allocation on `dev` can still get: the card's free memory plus what torch's allocator holds unused."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    return free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+
+
 class _TowerFn(torch.autograd.Function):
     """features = tower(inputs).  The tower's parameters are inputs of the node so that autograd knows the output
     depends on them; their gradients are returned to autograd, or added to the flat gradient buffer directly."""
@@ -344,14 +352,29 @@ class _TowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tower: TrainTower, run, chunks, *params):
         """run(lo, hi) -> (features, saved) for items lo..hi; chunks: list of (lo, hi).  With more than one chunk
-        nothing is saved and backward recomputes each chunk's forward (the reference wraps its feature calls in
-        torch.utils.checkpoint the same way, llava_clip_model_v3.py:52-83)."""
+        backward recomputes the forward of the chunks whose activations were not kept (the reference wraps its
+        feature calls in torch.utils.checkpoint the same way, llava_clip_model_v3.py:52-83)."""
         ctx.tower, ctx.run, ctx.chunks = tower, run, chunks
+        ctx.kept = {}
         if len(chunks) == 1:
+            tower.save_extras = bool(tower.recompute_chunk)
             feats, ctx.saved = run(*chunks[0])
             return feats
+        # Recompute costs a second forward, a quarter of the step's GEMM work, and is only worth it for the memory it
+        # frees: with 288 GB on the card most batches need little of it.  Chunks keep their saved sets (without the
+        # cheap extras) while the card's free memory stays above what the backward of a recomputed chunk needs.
         ctx.saved = None
-        return torch.cat([run(lo, hi)[0] for lo, hi in chunks], dim=0)
+        tower.save_extras = False
+        dev, feats, per = tower.device, [], 0
+        for idx, (lo, hi) in enumerate(chunks):
+            before = torch.cuda.memory_allocated(dev)
+            f, saved = run(lo, hi)
+            feats.append(f)
+            per = max(per, torch.cuda.memory_allocated(dev) - before)
+            if tower.keep_activations and _headroom(dev) > 2.5 * per + (12 << 30):
+                ctx.kept[idx] = saved
+            del saved
+        return torch.cat(feats, dim=0)
 
     @staticmethod
     def backward(ctx, dfeat):
@@ -360,9 +383,13 @@ class _TowerFn(torch.autograd.Function):
             ctx.tower.backward(ctx.saved, dfeat, sink)
             ctx.saved = None
         else:
-            for lo, hi in ctx.chunks:
-                _, saved = ctx.run(lo, hi)
+            for idx, (lo, hi) in enumerate(ctx.chunks):
+                saved = ctx.kept.pop(idx, None)
+                if saved is None:
+                    ctx.tower.save_extras = True
+                    _, saved = ctx.run(lo, hi)
                 ctx.tower.backward(saved, dfeat[lo:hi], sink)
+                del saved
         return (None, None, None) + tuple(sink.autograd_outputs())
 
 

@@ -107,23 +107,46 @@ def _grads_of(model):
     return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
 
 
+def _tower_nodes(outputs):
+    """The image/text tower nodes of the autograd graph behind a forward()'s outputs."""
+    seen, found, stack = set(), [], [getattr(outputs[3], "grad_fn", None)]
+    for d in list(outputs[0].values()) + list(outputs[1].values()) + list(outputs[2]):
+        stack.append(d.dense.grad_fn)
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        if hasattr(fn, "chunks"):
+            found.append(fn)
+        stack += [nf for nf, _ in fn.next_functions]
+    return found
+
+
 def test_flat_parameters_and_chunked_recompute_give_the_same_gradients():
     """The same batch through (a) loose parameters, (b) flat buffers with in-place gradient accumulation,
-    (c) flat buffers + image towers recomputed 5 crops at a time: same loss, same gradients (up to the order
-    of the fp32 atomic additions); two backward passes accumulate; state_dict survives flattening."""
+    (c) flat buffers + image towers run 5 crops at a time, every chunk recomputed in backward, (d) the same with the
+    chunks' activations kept while memory allows: same loss, same gradients (up to the order of the fp32 atomic
+    additions); two backward passes accumulate; state_dict survives flattening."""
     b = make_clip_batch(12, n_videos=1, frames=3, objects=3, H=96, W=128, k_cate=4, k_unary=5, k_binary=3, min_box=12,
                         max_box=90)
     kw = b.forward_kwargs()
     results = []
-    for mode in ("loose", "flat", "flat+recompute"):
+    for mode in ("loose", "flat", "flat+recompute", "flat+chunks kept"):
         cfg, sd, tok, model = _setup(24, float(np.log(10.0)))
         model.enable_training()
         if mode != "loose":
             flat = model.flatten_parameters()
             assert all(torch.equal(v.cpu(), sd[k]) for k, v in model.state_dict().items())
         if mode == "flat+recompute":
+            model.set_recompute_chunk(5, keep_activations=False)
+        if mode == "flat+chunks kept":
             model.set_recompute_chunk(5)
-        loss, _ = _loss(model(**kw), 3)
+        out = model(**kw)
+        if mode.startswith("flat+"):
+            fns = [f for f in _tower_nodes(out) if len(f.chunks) > 1]
+            assert fns and all(len(f.kept) == (len(f.chunks) if mode == "flat+chunks kept" else 0) for f in fns)
+        loss, _ = _loss(out, 3)
         loss.backward()
         torch.cuda.synchronize()
         results.append((loss.item(), _grads_of(model)))
@@ -134,9 +157,9 @@ def test_flat_parameters_and_chunked_recompute_give_the_same_gradients():
             assert ((flat.grad - 2 * once).norm() / (2 * once).norm()).item() <= 1e-4     # accumulation
             flat.zero_grad()
             assert float(flat.grad.abs().max()) == 0.0
-    (l0, g0), (l1, g1), (l2, g2) = results
-    assert abs(l0 - l1) <= 1e-5 * max(1, abs(l0)) and abs(l0 - l2) <= 1e-5 * max(1, abs(l0))
-    for other in (g1, g2):
+    (l0, g0), (l1, g1), (l2, g2), (l3, g3) = results
+    assert all(abs(l0 - l) <= 1e-5 * max(1, abs(l0)) for l in (l1, l2, l3))
+    for other in (g1, g2, g3):
         assert set(other) == set(g0)
         a = torch.cat([g0[k].reshape(-1) for k in sorted(g0)])
         o = torch.cat([other[k].reshape(-1) for k in sorted(g0)])

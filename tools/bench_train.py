@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--loose", action="store_true", help="separate parameter tensors instead of the flat buffers")
     ap.add_argument("--recompute", type=int, default=0, help="recompute the image towers in backward, N crops at a time")
+    ap.add_argument("--no-keep", action="store_true", help="with --recompute: recompute every chunk, keep no activations")
     ap.add_argument("--H", type=int, default=360)
     ap.add_argument("--W", type=int, default=640)
     a = ap.parse_args()
@@ -42,7 +43,7 @@ def main():
     flat = None if a.loose else model.flatten_parameters()
     opt = training.Adam(flat if flat is not None else model.parameters(), lr=1e-6)
     if a.recompute:
-        model.set_recompute_chunk(a.recompute)
+        model.set_recompute_chunk(a.recompute, keep_activations=not a.no_keep)
     b = make_clip_batch(5, n_videos=a.videos, frames=a.frames, objects=a.objects, H=a.H, W=a.W, k_cate=35, k_unary=50,
                         k_binary=50, min_box=24, max_box=min(a.H, a.W) - 8)
     kw = b.forward_kwargs()
