@@ -842,18 +842,41 @@ static __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0
 
 __device__ __forceinline__ int tn_swz(int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); }
 
-template <bool SYNC, bool DMA, bool READ>
+// The whole-stage kernel's DMA source of piece q = a uniform pointer (src[q]: the piece's first row, in SGPRs) + a 32-bit
+// per-lane offset that is the same for every piece of an operand: two VGPRs and no vector arithmetic.  (Per-lane 64-bit
+// pointers and their row-limit selects cost about 30 VGPRs around the fetch; that kernel spills, and the vmcnt(0) wait of
+// every reload in the loop also waits for the DMA just issued, so the fetch latency is no longer hidden.)
+struct TnSrc {
+    const unsigned char *src[8];   // q < 4: A pieces wave + 8 q, q >= 4: B pieces
+    unsigned voff_a, voff_b;
+};
+
+// 16 bytes per lane from base + voff to LDS at lds_addr + 16 * lane.  Assembly for the scalar-base form of the
+// instruction; M0 (the LDS address of the transfer) is used by nothing else in that kernel.
+__device__ __forceinline__ void tn_dma16(const unsigned char *base, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr));
+}
+
+// FAST: every stage lies inside the reduction range (t is used; goff .. row_lim are not).  Otherwise rows at or past
+// row_lim read zeros (t is not used).
+template <bool FAST, bool SYNC, bool DMA, bool READ>
 __device__ __forceinline__ void tn_substep(f32x4 (&acc)[4][8], const bf16x8 (&ca)[4], const bf16x8 (&cb)[8],
                                            bf16x8 (&na)[4], bf16x8 (&nb)[8], const unsigned char *rd_row, int a_x, int b_x,
                                            unsigned char *wr_slot, const unsigned (&goff)[8], const unsigned char *abase,
-                                           const unsigned char *bbase, const unsigned char *zero, unsigned row_lim, int wave) {
+                                           const unsigned char *bbase, const unsigned char *zero, unsigned row_lim, int wave,
+                                           const TnSrc &t) {
     if (SYNC) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    if (DMA) {
+    if (DMA && FAST) {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            tn_dma16(t.src[q], q < 4 ? t.voff_a : t.voff_b, (unsigned)(uintptr_t)LDS_PTR(wr_slot + (wave + 8 * q) * 1024));
+    }
+    if (DMA && !FAST) {
         // rows at or past row_lim (the reduction rows left in this workgroup's range) read zeros
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -885,7 +908,7 @@ __device__ __forceinline__ void tn_substep(f32x4 (&acc)[4][8], const bf16x8 (&ca
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
-    if (DMA) {
+    if (DMA && !FAST) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
@@ -901,6 +924,8 @@ __device__ __forceinline__ void tn_substep(f32x4 (&acc)[4][8], const bf16x8 (&ca
     }
 }
 
+// FAST: the host promises that every workgroup's reduction range is a multiple of 64 rows, at least 128
+template <bool FAST>
 __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -923,8 +948,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmArgs g) {
     // DMA piece p (32 per operand and stage) = stage rows 2p, 2p + 1; lane -> row 2p + (lane >> 5), LDS chunk position
     // lane & 31, which holds source chunk (lane & 31) ^ swz(row).  q < 4: A pieces wave + 8 q; q >= 4: B pieces.
     unsigned goff[8];
+    TnSrc t;
+    if (FAST) {
+        // swz(row) only looks at row bits 0, 1 and 3, which the 16 q rows between a wave's pieces leave alone: the
+        // per-lane part of the offset is that of piece q = 0
+        const int c = (lane & 31) ^ tn_swz(2 * wave + (lane >> 5));
+        const int ca = m0 + c * 8, cb = n0 + c * 8;          // past the matrix: any valid chunk (never stored)
+        t.voff_a = ((unsigned)(lane >> 5) * (unsigned)g.lda + (unsigned)(ca < g.M ? ca : g.M - 8)) * 2u;
+        t.voff_b = ((unsigned)(lane >> 5) * (unsigned)g.ldw + (unsigned)(cb < g.N ? cb : g.N - 8)) * 2u;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < 8; q++) {
+            const size_t row = (size_t)k_begin + 2 * wave + 16 * (q & 3);
+            t.src[q] = (const unsigned char *)(q < 4 ? g.A + row * g.lda : g.W + row * g.ldw);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8 && !FAST; q++) {
         const bool isb = q >= 4;
         const int row = 2 * (wave + 8 * (q & 3)) + (lane >> 5);
         const int c = (lane & 31) ^ tn_swz(row);
@@ -945,20 +984,33 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmArgs g) {
     const int a_x = (((wm * 8 + (tp >> 1)) ^ tn_swz(frow)) << 4);
     const int b_x = (((wn * 16 + (tp >> 1)) ^ tn_swz(frow)) << 4);
 
+    auto advance = [&]() {
+        if (FAST) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) t.src[q] += q < 4 ? astep : bstep;
+        } else {
+            abase += astep;
+            bbase += bstep;
+        }
+    };
     // stages 0 and 1
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const unsigned lim = (unsigned)max(0, min(64, k_len - 64 * t));
+    for (int st = 0; st < 2; st++) {
+        const unsigned lim = (unsigned)max(0, min(64, k_len - 64 * st));
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            const unsigned row = 2u * (unsigned)(wave + 8 * (q & 3)) + ((unsigned)lane >> 5);
-            const unsigned char *src = (q < 4 ? abase + t * astep : bbase + t * bstep) + goff[q];
-            src = row < lim ? src : zero;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds + t * P64_SLOT + (wave + 8 * q) * 1024), 16, 0, 0);
+            if (FAST) {
+                tn_dma16(t.src[q], q < 4 ? t.voff_a : t.voff_b,
+                         (unsigned)(uintptr_t)LDS_PTR(lds + st * P64_SLOT + (wave + 8 * q) * 1024));
+            } else {
+                const unsigned row = 2u * (unsigned)(wave + 8 * (q & 3)) + ((unsigned)lane >> 5);
+                const unsigned char *src = (q < 4 ? abase : bbase) + goff[q];
+                src = row < lim ? src : zero;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(lds + st * P64_SLOT + (wave + 8 * q) * 1024), 16, 0, 0);
+            }
         }
+        advance();
     }
-    abase += 2 * (size_t)astep;
-    bbase += 2 * (size_t)bstep;
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -983,22 +1035,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmArgs g) {
     for (; s < ns - 2; s++) {
         unsigned char *cur = lds + (s & 1) * P64_SLOT, *nxt = lds + ((s + 1) & 1) * P64_SLOT;
         const unsigned lim = (unsigned)max(0, min(64, k_len - 64 * (s + 2)));
-        tn_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
-                                       zero, lim, wave);
-        tn_substep<true, true, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + row_off, a_x, b_x, cur, goff, abase, bbase, zero, lim,
-                                     wave);
-        abase += astep;
-        bbase += bstep;
+        tn_substep<FAST, false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
+                                       zero, lim, wave, t);
+        tn_substep<FAST, true, true, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + row_off, a_x, b_x, cur, goff, abase, bbase, zero, lim,
+                                     wave, t);
+        advance();
     }
     {
         unsigned char *cur = lds + (s & 1) * P64_SLOT, *nxt = lds + ((s + 1) & 1) * P64_SLOT;
-        tn_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
-                                       zero, 0u, wave);
-        tn_substep<true, false, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + row_off, a_x, b_x, cur, goff, abase, bbase, zero, 0u,
-                                      wave);
-        tn_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], nxt + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
-                                       zero, 0u, wave);
-        tn_substep<false, false, false>(acc, fa[1], fb[1], fa[0], fb[0], nxt, a_x, b_x, cur, goff, abase, bbase, zero, 0u, wave);
+        tn_substep<FAST, false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
+                                       zero, 0u, wave, t);
+        tn_substep<FAST, true, false, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + row_off, a_x, b_x, cur, goff, abase, bbase, zero, 0u,
+                                      wave, t);
+        tn_substep<FAST, false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], nxt + 16384 + row_off, a_x, b_x, cur, goff, abase, bbase,
+                                       zero, 0u, wave, t);
+        tn_substep<FAST, false, false, false>(acc, fa[1], fb[1], fa[0], fb[0], nxt, a_x, b_x, cur, goff, abase, bbase, zero, 0u, wave, t);
     }
     __syncthreads();
     epilogue_passes<SGCLIP_EPI_F32_ATOMIC, 4, 8>(g, acc, (float *)(lds + wave * epi_pass_bytes(8)), m0 + wm * 64, n0 + wn * 128,
@@ -1236,17 +1287,32 @@ extern "C" int sgclip_gemm_tn_bf16(const void *A_dev, int lda, const void *B_dev
         const char *e = getenv("SGCLIP_TN_WGS");
         target = e ? atoi(e) : 256;
     }
-    const long tiles = (long)g.tiles_m * g.tiles_n;
-    int splits = (int)std::max(1L, std::min((long)ceil_div(Kd, 512), target / tiles));
-    const int kc = ceil_div(ceil_div(Kd, splits), 64) * 64;
-    splits = ceil_div(Kd, kc);
-    g.K = kc;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P64_SLOT);
+        (void)hipFuncSetAttribute((const void *)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P64_SLOT);
+        (void)hipFuncSetAttribute((const void *)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P64_SLOT);
         attr = true;
     }
+    const long tiles = (long)g.tiles_m * g.tiles_n;
     KernelTimer timer(TK_GEMM0 + SGCLIP_EPI_F32_ATOMIC, 2.0 * M * N * Kd, stream);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(512), 2 * P64_SLOT, stream, g);
+    // Whole 64-row stages go to the kernel that assumes them (every slice a multiple of 64 rows, at least two stages);
+    // the last Kd % 64 rows, or a reduction shorter than two stages, to the one that checks every row.
+    const int kd_main = Kd / 64 * 64 >= 128 ? Kd / 64 * 64 : 0;
+    if (kd_main) {
+        int splits = (int)std::max(1L, std::min((long)ceil_div(kd_main, 512), target / tiles));
+        int kc = ceil_div(ceil_div(kd_main, splits), 64) * 64;
+        while (kd_main % kc == 64) kc += 64;   // the last slice needs two stages as well
+        splits = ceil_div(kd_main, kc);
+        g.k_total = kd_main;
+        g.K = kc;
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)tiles, (unsigned)splits), dim3(512), 2 * P64_SLOT, stream, g);
+    }
+    if (Kd > kd_main) {
+        g.A = (const bf16_t *)A_dev + (size_t)kd_main * lda;
+        g.W = (const bf16_t *)B_dev + (size_t)kd_main * ldb;
+        g.k_total = Kd - kd_main;   // at most 127 rows
+        g.K = 128;
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3((unsigned)tiles, 1), dim3(512), 2 * P64_SLOT, stream, g);
+    }
     return launch_check("sgclip_gemm_tn_bf16");
 }

@@ -84,9 +84,12 @@ def test_gemm_split_k_accumulates_atomically(dev, M, N, K):
 
 
 @pytest.mark.parametrize("Kd,M,N", [(64, 256, 256), (128, 16, 8), (51200, 768, 768), (6400, 2304, 768), (1425, 520, 264),
-                                    (37, 64, 128), (1000, 3072, 768), (4099, 768, 3072)])
+                                    (37, 64, 128), (1000, 3072, 768), (4099, 768, 3072), (127, 264, 520), (129, 264, 520),
+                                    (191, 256, 256), (3648, 256, 256), (3648 + 9, 768, 768)])
 def test_gemm_tn_accumulates_a_transposed_product(dev, Kd, M, N):
-    """sgclip_gemm_tn_bf16: C += A^T B from row-major operands, any reduction length, partial tiles, strided rows."""
+    """sgclip_gemm_tn_bf16: C += A^T B from row-major operands, any reduction length, partial tiles, strided rows.
+    Whole 64-row stages run on one kernel and the remaining rows on another; 3648 rows would leave a last reduction
+    slice of a single stage without the host's adjustment."""
     a = _randn((Kd, M + 8), dev, 61, 1.0, torch.bfloat16)[:, :M]
     b = _randn((Kd, N), dev, 62, 1.0, torch.bfloat16)
     c0 = _randn((M, N), dev, 63, 1.0)
