@@ -44,6 +44,7 @@ struct GemmArgs {
     int wide_epilogue;  // N % 8 == 0, ldc % 8 == 0 and C, bias, aux 16-byte aligned
     int debug_mode;     // diagnostics only: 1 = skip epilogue stores, 2 = single K step
     float *colsum;      // EPI_MULGRAD through epilogue_passes: += column sums of C (null: none)
+    int tn_gm, tn_gn, tn_upx;   // gemm_tn_kernel: tile group shape and (group, slice) units per XCD (tn_gm = 0: plain grid)
 };
 
 // one 1 KiB piece (8 rows x 128 B) of an operand tile: lane -> (row, swizzled chunk)
@@ -931,10 +932,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 rows x 128 columns of C
-    const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x - tm * g.tiles_n;
+    // Workgroups are dealt to the 8 XCDs round robin and every XCD has its own L2.  A unit = a group of tn_gm x tn_gn
+    // tiles on one reduction slice: its workgroups walk the same rows of tn_gm + tn_gn operand panels side by side, so
+    // with a unit's workgroups on ONE XCD (tn_upx units each) its L2 fetches every panel row once.
+    int tm, tn, split;
+    if (g.tn_gm) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int gsz = g.tn_gm * g.tn_gn;
+        const int ul = slot / gsz, tig = slot - ul * gsz;
+        const int unit = xcd * g.tn_upx + ul;
+        const int groups_n = g.tiles_n / g.tn_gn, groups = (g.tiles_m / g.tn_gm) * groups_n;
+        split = unit / groups;
+        const int grp = unit - split * groups;
+        const int gmi = grp / groups_n, gni = grp - gmi * groups_n;
+        const int tim = tig / g.tn_gn;
+        tm = gmi * g.tn_gm + tim;
+        tn = gni * g.tn_gn + (tig - tim * g.tn_gn);
+    } else {
+        tm = blockIdx.x / g.tiles_n;
+        tn = blockIdx.x - tm * g.tiles_n;
+        split = blockIdx.y;
+    }
     const int m0 = tm * 256, n0 = tn * 256;
-    // reduction range of this workgroup: g.K rows from blockIdx.y * g.K (a multiple of 64), cut at k_total
-    const int k_begin = blockIdx.y * g.K;
+    // reduction range of this workgroup: g.K rows from split * g.K (a multiple of 64), cut at k_total
+    const int k_begin = split * g.K;
     const int k_len = min(g.K, g.k_total - k_begin);
     const int ns = max(2, (k_len + 63) / 64);   // a second stage of zeros when the range is that short
 
@@ -1254,6 +1275,79 @@ extern "C" int sgclip_gemm_mulgelugrad_bf16(const void *A_dev, int lda, const vo
     return rc;
 }
 
+namespace sgclip {
+
+// Launch plan of the whole-stage weight-gradient kernel.  The plain grid (tile fastest, slices on blockIdx.y) fills the
+// CUs best but scatters the tiles that share an operand panel over the XCDs: every XCD then pulls most panels through
+// its own L2 and the launch runs at the rate of the fabric behind the L2s.  The grouped grid keeps gm x gn tiles of one
+// slice on one XCD (at most 32 workgroups there, one per CU).  Both are priced with the rates measured on MI355X
+// (1.24 PFLOP/s per fully used chip, 5.9 TB/s into the L2s) and the cheaper one is launched.
+struct TnPlan {
+    int gm = 0, gn = 0, upx = 0, splits = 1, kc = 0;
+    double cost = 1e30;
+};
+
+static int tn_slice_rows(int kd, int &splits) {   // slices of whole stages, the last at least two stages
+    int kc = ceil_div(ceil_div(kd, splits), 64) * 64;
+    while (kd % kc == 64) kc += 64;
+    splits = ceil_div(kd, kc);
+    return kc;
+}
+
+static TnPlan tn_plan(int tiles_m, int tiles_n, int kd, int target_wgs) {
+    const double flops = 2.0 * 256 * 256 * (double)kd * tiles_m * tiles_n, panel_bytes_per_row = 512.0;
+    auto price = [&](double util, double panels_fetched_rows) {
+        const double fetch = panels_fetched_rows * panel_bytes_per_row / 5.9e12;
+        return std::max(flops / (1.24e15 * util), fetch) + 0.1 * fetch;   // of two compute-bound plans, the one that fetches less
+    };
+    TnPlan best;
+    {   // plain grid: per XCD and slice, the distinct panels of the tiles t with (t + tiles * slice) % 8 == xcd
+        const int tiles = tiles_m * tiles_n;
+        int splits = (int)std::max(1L, std::min((long)ceil_div(kd, 512), (long)target_wgs / tiles));
+        const int kc = tn_slice_rows(kd, splits);
+        double panel_rows = 0;
+        for (int sl = 0; sl < splits; sl++) {
+            const int rows = std::min(kc, kd - sl * kc);
+            for (int x = 0; x < 8; x++) {
+                unsigned long long ms = 0, ns = 0;   // tiles_m, tiles_n <= 64 here, else no set is kept (all distinct)
+                int cnt = 0;
+                for (int t = 0; t < tiles; t++)
+                    if ((t + tiles * sl) % 8 == x) {
+                        ms |= 1ull << ((t / tiles_n) & 63);
+                        ns |= 1ull << ((t % tiles_n) & 63);
+                        cnt++;
+                    }
+                const int distinct = tiles_m <= 64 && tiles_n <= 64 ? __builtin_popcountll(ms) + __builtin_popcountll(ns) : 2 * cnt;
+                panel_rows += (double)distinct * rows;
+            }
+        }
+        const long wgs = (long)tiles * splits;
+        const double util = (double)wgs / (ceil_div(wgs, 256) * 256.0);
+        best.splits = splits, best.kc = kc, best.cost = price(util, panel_rows);
+    }
+    for (int gm = 1; gm <= tiles_m; gm++) {
+        if (tiles_m % gm) continue;
+        for (int gn = 1; gn <= tiles_n; gn++) {
+            if (tiles_n % gn || gm * gn > 32) continue;
+            const int groups = (tiles_m / gm) * (tiles_n / gn);
+            for (int upx = 32 / (gm * gn); upx >= 1; upx--) {
+                if ((8 * upx) % groups) continue;
+                int splits = 8 * upx / groups;
+                if (splits > ceil_div(kd, 512) && splits > 1) continue;
+                const int want = splits;
+                const int kc = tn_slice_rows(kd, splits);
+                if (splits != want) continue;   // every unit needs its slice
+                const double cost = price(gm * gn * upx / 32.0, (double)(gm + gn) * groups * kd);
+                if (cost < best.cost * 0.97) best = TnPlan{gm, gn, upx, splits, kc, cost};   // a tie goes to the plain grid
+                break;
+            }
+        }
+    }
+    return best;
+}
+
+}  // namespace sgclip
+
 extern "C" int sgclip_gemm_tn_bf16(const void *A_dev, int lda, const void *B_dev, int ldb, float *C_dev, int ldc, int M, int N,
                                    int Kd, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1299,13 +1393,23 @@ extern "C" int sgclip_gemm_tn_bf16(const void *A_dev, int lda, const void *B_dev
     // the last Kd % 64 rows, or a reduction shorter than two stages, to the one that checks every row.
     const int kd_main = Kd / 64 * 64 >= 128 ? Kd / 64 * 64 : 0;
     if (kd_main) {
-        int splits = (int)std::max(1L, std::min((long)ceil_div(kd_main, 512), target / tiles));
-        int kc = ceil_div(ceil_div(kd_main, splits), 64) * 64;
-        while (kd_main % kc == 64) kc += 64;   // the last slice needs two stages as well
-        splits = ceil_div(kd_main, kc);
+        static int grouped = -1;
+        if (grouped < 0) {
+            const char *e = getenv("SGCLIP_TN_GROUPED");
+            grouped = e ? atoi(e) : 1;
+        }
+        TnPlan plan = tn_plan(g.tiles_m, g.tiles_n, kd_main, target);
+        if (!grouped && plan.gm) {
+            plan = TnPlan();
+            plan.splits = (int)std::max(1L, std::min((long)ceil_div(kd_main, 512), target / tiles));
+            plan.kc = tn_slice_rows(kd_main, plan.splits);
+        }
         g.k_total = kd_main;
-        g.K = kc;
-        hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)tiles, (unsigned)splits), dim3(512), 2 * P64_SLOT, stream, g);
+        g.K = plan.kc;
+        g.tn_gm = plan.gm, g.tn_gn = plan.gn, g.tn_upx = plan.upx;
+        const dim3 grid = plan.gm ? dim3((unsigned)(8 * plan.upx * plan.gm * plan.gn), 1) : dim3((unsigned)tiles, (unsigned)plan.splits);
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(512), 2 * P64_SLOT, stream, g);
+        g.tn_gm = 0;
     }
     if (Kd > kd_main) {
         g.A = (const bf16_t *)A_dev + (size_t)kd_main * lda;
