@@ -170,6 +170,7 @@ struct CropArgs {
     int ksx_cap, ksy_cap, wn_cap;
     int need_lo, need_hi;  // this launch handles the crops whose own LDS need is in (need_lo, need_hi]
     int nseg;              // column segments (segmented launch only; 1 otherwise)
+    int mfma_split;        // 1: crops that crop_mfma_ok() accepts belong to crop_mfma_kernel, the others to crop_kernel
 };
 
 // output columns of segment s: [seg_begin(s), seg_begin(s + 1)); column c lies in segment c * nseg / S
@@ -183,6 +184,69 @@ __host__ __device__ inline int crop_need(int w, int h, int S, int vrows) {
     axis_bounds(w, new_w, left, x0, n0);
     axis_bounds(w, new_w, left + S - 1, x1, n1);
     return crop_lds(S, axis_ksize(w, new_w), axis_ksize(h, new_h), x1 + n1 - x0, vrows).total;
+}
+
+// ---- the matrix-core variant (crop_mfma_kernel below): LDS layout, eligibility -------------------------------------
+constexpr int MR = 16;        // source rows per chunk
+constexpr int NTM = 512;      // threads per workgroup: 8 waves, each owns up to 3 blocks of 16 output columns
+constexpr int MKB = 2;        // 64-pixel source windows per block of 16 output columns
+
+struct CropLdsM {
+    int lut8, norm, xmin, xcnt, ymin, ycnt, kv, raw, ma, mb, planes, kh, total;
+    int raw_stride, m_stride, pst;
+};
+
+__host__ __device__ inline CropLdsM crop_lds_m(int S, int ksx, int ksy, int wn, int vrows) {
+    CropLdsM L;
+    int o = 0;
+    L.lut8 = o; o += 1024;   // the three level tables and the identity
+    L.norm = o; o += 768 * 4;
+    L.xmin = o; o += al16(S * 4);
+    L.xcnt = o; o += al16(S * 4);
+    L.ymin = o; o += al16(vrows * 4);
+    L.ycnt = o; o += al16(vrows * 4);
+    L.kv = o; o += al16(vrows * ksy * 4);
+    // a blend item is four pixels read as whole dwords: the last one of a row may read up to three pixels and one
+    // dword past the span
+    L.raw_stride = al16(wn * 3 + 3 + 9 + 4);
+    L.m_stride = al16(wn + 3 + 3 + 4);
+    L.raw = o; o += MR * L.raw_stride;
+    L.ma = o; o += MR * L.m_stride;
+    L.mb = o; o += MR * L.m_stride;
+    // channel planes [3][MR][pst] of blended bytes; the horizontal coefficient table is only read while the per-wave
+    // operands are built and the band's output staging only after its last chunk, so both share the planes' bytes.
+    // A block's 128-byte window may start anywhere in a row: the last row needs that much room behind it.
+    L.pst = al16(wn + 3) + 16;
+    int body = 3 * MR * L.pst + 64 * MKB;
+    if (body < al16(ksx * S * 4)) body = al16(ksx * S * 4);
+    if (body < BR * 3 * S * 2) body = BR * 3 * S * 2;
+    L.planes = o; L.kh = o; o += body;
+    L.total = o;
+    return L;
+}
+
+__host__ __device__ inline int crop_need_m(int w, int h, int S, int vrows) {
+    int new_w, new_h, top, left;
+    crop_geom(w, h, S, new_w, new_h, top, left);
+    int x0, n0, x1, n1;
+    axis_bounds(w, new_w, left, x0, n0);
+    axis_bounds(w, new_w, left + S - 1, x1, n1);
+    return crop_lds_m(S, axis_ksize(w, new_w), axis_ksize(h, new_h), x1 + n1 - x0, vrows).total;
+}
+
+// Whether crop_mfma_kernel takes the crop: at most 24 column blocks, and the source pixels under any 16 neighbouring
+// output columns (15 column steps of `scale` pixels, the taps of the last one, up to 15 pixels of alignment and one of
+// rounding on either side) fit MKB windows of 64 pixels.  The kernel re-checks the exact spans and leaves the output
+// untouched if this bound were ever wrong, so a miss shows in the parity tests.
+__host__ __device__ inline bool crop_mfma_ok(int w, int h, int S, int vrows) {
+#pragma clang fp contract(off)
+    if (S > 16 * 24) return false;
+    int new_w, new_h, top, left;
+    crop_geom(w, h, S, new_w, new_h, top, left);
+    const double scale = (double)w / new_w;
+    const double span = 15.0 * scale + axis_ksize(w, new_w) + 17.0;
+    if (span > 64.0 * MKB) return false;
+    return crop_need_m(w, h, S, vrows) <= LDS_LIMIT;
 }
 
 __device__ __forceinline__ int clip8(int v) {
@@ -211,6 +275,7 @@ __global__ __launch_bounds__(NT, 4) void crop_kernel(CropArgs a) {
     const sgclip_crop_t c = a.crops[crop_i];
     const int S = a.S;
     const int w = c.x2 - c.x1, h = c.y2 - c.y1;
+    if (a.mfma_split && crop_mfma_ok(w, h, S, vrows)) return;
     {   // crops are binned by LDS need so that small crops run at high occupancy
         const int need = crop_need(w, h, S, vrows);
         if (need <= a.need_lo || need > a.need_hi) return;
@@ -553,6 +618,388 @@ __global__ __launch_bounds__(NT, 4) void crop_kernel(CropArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// The same crop on the matrix cores.  Pillow's two resampling passes are integer matrix products with banded
+// coefficient matrices: row pass  H[y][c] = clip8((2^21 + sum_x P[y][x] K[x][c]) >> 22), column pass likewise over y.
+// v_mfma_i32_16x16x64_i8 multiplies signed bytes exactly, so
+//   * pixels are held as p - 128 (the constant 128 * sum of a column's coefficients goes into the accumulator start),
+//   * every 22-bit coefficient is three signed byte digits d0 + 2^8 d1 + 2^16 d2: three products, recombined with shifts.
+// A wave owns NBW blocks of 16 output columns.  Its B operands of the row pass (the digits of the coefficients of its
+// columns over a window of MKB * 64 source pixels that starts at a 16-byte boundary) are built once per workgroup and
+// stay in registers.  Per chunk of MR = 16 source rows:
+//   A  DMA of the chunk's frame and mask rows into LDS (issued one chunk ahead)
+//   B  blend: work item = 4 neighbouring pixels of a row -> one dword per channel plane [channel][row][x]
+//   C  per channel and block: A operand = 16 rows x 64 pixels straight from the plane (ds_read_b128), 3 digit products;
+//      the result lane holds 4 neighbouring rows of one column: clipped and packed, that dword IS the B operand of
+//   D  the column pass (K slot (g, j < 4) <-> chunk row 4g + j, the other slots zero), A operand = the digits of this
+//      band's vertical coefficients for the chunk's rows; accumulated per lane for 4 output rows of its column.
+// No pass-C output goes through LDS and there is no barrier between C and D; two barriers per chunk.
+// ---------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// c = d0 + 256 d1 + 65536 d2 with d0, d1 in [-128, 127] (|c| < 2^23: d2 fits a signed byte as well)
+__device__ __forceinline__ void byte_digits(int c, int &d0, int &d1, int &d2) {
+    d0 = (int)(signed char)(c & 255);
+    const int c1 = (c - d0) >> 8;
+    d1 = (int)(signed char)(c1 & 255);
+    d2 = (c1 - d1) >> 8;
+}
+
+template <int NBW>
+__global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bpw = a.bands_per_wg;
+    const int wg_per_crop = a.nbands / bpw;
+    const int crop_i = blockIdx.x / wg_per_crop;
+    const int band0 = (blockIdx.x - crop_i * wg_per_crop) * bpw;
+    const int vrows = bpw * BR;
+    const sgclip_crop_t c = a.crops[crop_i];
+    const int S = a.S;
+    const int w = c.x2 - c.x1, h = c.y2 - c.y1;
+    if (!crop_mfma_ok(w, h, S, vrows)) return;
+    {
+        const int need = crop_need_m(w, h, S, vrows);
+        if (need <= a.need_lo || need > a.need_hi) return;
+    }
+    int new_w, new_h, top, left;
+    crop_geom(w, h, S, new_w, new_h, top, left);
+
+    const CropLdsM L = crop_lds_m(S, a.ksx_cap, a.ksy_cap, a.wn_cap, vrows);
+    uint8_t *lut8 = smem + L.lut8;
+    float *norm = (float *)(smem + L.norm);
+    int *xmin = (int *)(smem + L.xmin);
+    int *xcnt = (int *)(smem + L.xcnt);
+    int *kh = (int *)(smem + L.kh);
+    int *ymin = (int *)(smem + L.ymin);
+    int *ycnt = (int *)(smem + L.ycnt);
+    int *kv = (int *)(smem + L.kv);
+    uint8_t *raw = smem + L.raw;
+    uint8_t *ma = smem + L.ma;
+    uint8_t *mb = smem + L.mb;
+    uint8_t *planes = smem + L.planes;
+    const int PST = L.pst;
+
+    // ---- setup: level tables and both axes' coefficients (once per workgroup)
+    if (tid < 192) __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a.lut8 + tid * 4), LDS_PTR(lut8 + wave * 256), 4, 0, 0);
+    if (tid < 256) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a.normlut + i * 256 + tid), LDS_PTR(norm + i * 256 + wave * 64), 4, 0, 0);
+    }
+    if (tid < 64) ((unsigned *)(lut8 + 768))[tid] = 0x03020100u + 0x04040404u * (unsigned)tid;   // identity table
+    for (int col = tid; col < S; col += NTM) {
+        int xm, n;
+        axis_coeffs(w, new_w, left + col, xm, n, kh + col, S);
+        xmin[col] = xm;
+        xcnt[col] = n;
+    }
+    for (int vr = NTM - 1 - tid; vr < vrows; vr += NTM) {
+        int ym, n;
+        axis_coeffs(h, new_h, top + band0 * BR + vr, ym, n, kv + vr, vrows);
+        ymin[vr] = ym;
+        ycnt[vr] = n;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int cx0 = __builtin_amdgcn_readfirstlane(xmin[0]);
+    const int wn = __builtin_amdgcn_readfirstlane(xmin[S - 1] + xcnt[S - 1]) - cx0;
+    const int nblocks = (S + 15) >> 4;
+    bool fits = wn <= a.wn_cap;
+    for (int nb = 0; nb < nblocks; nb++) {   // uniform: every wave reaches the same verdict
+        const int cl = min(16 * nb + 15, S - 1);
+        const int lo = (__builtin_amdgcn_readfirstlane(xmin[16 * nb]) - cx0) & ~15;
+        const int hi = __builtin_amdgcn_readfirstlane(xmin[cl] + xcnt[cl]) - cx0;
+        fits = fits && hi - lo <= 64 * MKB;
+    }
+    if (!fits) return;   // host sizing and crop_mfma_ok guarantee this never triggers
+
+    // ---- this wave's column blocks: window start, coefficient digits (B operands), accumulator start
+    const int fr = lane & 15, kg = lane >> 4;
+    const int nb_mine = max(0, min(NBW, nblocks - wave * NBW));
+    int x0[NBW], hstart[NBW];
+    v4i bco[NBW][MKB][3];
+#pragma unroll
+    for (int nbi = 0; nbi < NBW; nbi++) {
+        const int nb = min(wave * NBW + nbi, nblocks - 1);
+        const int colr = 16 * nb + fr;
+        const bool valid = nbi < nb_mine && colr < S;
+        const int col = min(colr, S - 1);
+        x0[nbi] = (__builtin_amdgcn_readfirstlane(xmin[16 * nb]) - cx0) & ~15;
+        const int xm = xmin[col] - cx0, n = valid ? xcnt[col] : 0;
+        int ksum = 0;
+        for (int t = 0; t < n; t++) ksum += kh[t * S + col];
+        hstart[nbi] = (1 << (PREC - 1)) + 128 * ksum;
+#pragma unroll
+        for (int kb = 0; kb < MKB; kb++) {
+            unsigned pk[3][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) pk[0][q] = pk[1][q] = pk[2][q] = 0u;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int t = x0[nbi] + 64 * kb + 16 * kg + j - xm;
+                const int cf = (t >= 0 && t < n) ? kh[t * S + col] : 0;
+                int d0, d1, d2;
+                byte_digits(cf, d0, d1, d2);
+                pk[0][j >> 2] |= (unsigned)(d0 & 255) << (8 * (j & 3));
+                pk[1][j >> 2] |= (unsigned)(d1 & 255) << (8 * (j & 3));
+                pk[2][j >> 2] |= (unsigned)(d2 & 255) << (8 * (j & 3));
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++) bco[nbi][kb][d] = (v4i){(int)pk[d][0], (int)pk[d][1], (int)pk[d][2], (int)pk[d][3]};
+        }
+    }
+    __syncthreads();   // the coefficient table is dead from here on: its bytes become the planes
+
+    const int mode = c.mode;
+    const uint8_t *fbase = a.frames + c.frame_off;
+    const uint8_t *mabase = a.masks + c.mask_a_off;
+    const uint8_t *mbbase = a.masks + c.mask_b_off;
+
+    auto copy_row = [&](const uint8_t *src, int nbytes, uint8_t *dst) {
+        const int lead = (int)((uintptr_t)src & 3);
+        const uint8_t *s0 = src - lead;
+        const int npiece = (lead + nbytes + 15) >> 4;
+        for (int i = 0; i < npiece; i += 64)
+            if (i + lane < npiece)
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(s0 + (size_t)(i + lane) * 16), LDS_PTR(dst + i * 16), 16, 0, 0);
+    };
+    auto issue_chunk = [&](int cy, int cy_end) {
+        const int nrows = min(MR, cy_end - cy);
+        for (int r = wave; r < nrows; r += NTM / 64) {
+            const size_t pix0 = (size_t)(c.y1 + cy + r) * c.frame_w + (c.x1 + cx0);
+            copy_row(fbase + pix0 * 3, wn * 3, raw + r * L.raw_stride);
+            if (mode != SGCLIP_CROP_PLAIN) {
+                copy_row(mabase + pix0, wn, ma + r * L.m_stride);
+                if (mode == SGCLIP_CROP_PAIR) copy_row(mbbase + pix0, wn, mb + r * L.m_stride);
+            }
+        }
+    };
+    auto band_rows = [&](int bl, int &r0, int &r1) {
+        r0 = __builtin_amdgcn_readfirstlane(ymin[bl * BR]);
+        r1 = __builtin_amdgcn_readfirstlane(ymin[bl * BR + BR - 1] + ycnt[bl * BR + BR - 1]);
+    };
+
+    const int patch = a.patch;
+    const bool patches = a.layout == SGCLIP_LAYOUT_PATCHES;
+    const int G = patches ? S / patch : 1;
+    const bool wide = a.out_dtype == SGCLIP_DTYPE_BF16 && ((uintptr_t)a.out & 15) == 0 &&
+                      (!patches || ((patch & 7) == 0 && (a.kpad & 7) == 0));
+    const v4i zero4 = {0, 0, 0, 0};
+
+    int ry0, ry1;
+    band_rows(0, ry0, ry1);
+    issue_chunk(ry0, ry1);
+    for (int bl = 0; bl < bpw; bl++) {
+        const int band = band0 + bl;
+        // this lane's output rows in the column pass: 4 kg + e; its A-operand row there: fr
+        v4i vsum[3][NBW];
+        {
+            int vstart[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int orow = bl * BR + 4 * kg + e;
+                const int n = ycnt[orow];
+                int ks = 0;
+                for (int t = 0; t < n; t++) ks += kv[t * vrows + orow];
+                vstart[e] = (1 << (PREC - 1)) + 128 * ks;
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                for (int nbi = 0; nbi < NBW; nbi++) vsum[ch][nbi] = (v4i){vstart[0], vstart[1], vstart[2], vstart[3]};
+        }
+        const int a_ym = ymin[bl * BR + fr], a_yn = ycnt[bl * BR + fr];
+        int nry0 = 0, nry1 = 0;
+        if (bl + 1 < bpw) band_rows(bl + 1, nry0, nry1);
+
+        for (int cy = ry0; cy < ry1; cy += MR) {
+            const int nrows = min(MR, ry1 - cy);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // ---- B: blend; 32 threads per row, an item = 4 pixels (rows past nrows keep stale bytes: the column
+            // pass has no coefficient for them, and integers have no NaN).  The LDS is this pass's bottleneck, so the
+            // 12 frame bytes and 4 + 4 mask bytes of an item come in as whole dwords (shifted into place by the row's
+            // byte offset), every channel goes through exactly one table read -- the identity table where the
+            // reference leaves the level alone -- and nothing branches per pixel.
+            {
+                const int r = tid >> 5;
+                if (r < nrows) {
+                    const size_t pix0 = (size_t)(c.y1 + cy + r) * c.frame_w + (c.x1 + cx0);
+                    const unsigned lead = (unsigned)((uintptr_t)(fbase + pix0 * 3) & 3);
+                    const unsigned ml = (unsigned)((uintptr_t)(mabase + pix0) & 3), bo = (unsigned)((uintptr_t)(mbbase + pix0) & 3);
+                    const unsigned *raw32 = (const unsigned *)(raw + r * L.raw_stride);
+                    const unsigned *ma32 = (const unsigned *)(ma + r * L.m_stride);
+                    const unsigned *mb32 = (const unsigned *)(mb + r * L.m_stride);
+                    unsigned *p0 = (unsigned *)(planes + (0 * MR + r) * PST);
+                    unsigned *p1 = (unsigned *)(planes + (1 * MR + r) * PST);
+                    unsigned *p2 = (unsigned *)(planes + (2 * MR + r) * PST);
+                    const int nq = (wn + 3) >> 2;
+                    auto blend = [&](auto mode_c) {
+                        constexpr int MODE = decltype(mode_c)::value;
+                        for (int xq = tid & 31; xq < nq; xq += 32) {
+                            const unsigned w0 = raw32[3 * xq], w1 = raw32[3 * xq + 1], w2 = raw32[3 * xq + 2], w3 = raw32[3 * xq + 3];
+                            // bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                            const unsigned q0 = __builtin_amdgcn_alignbyte(w1, w0, lead), q1 = __builtin_amdgcn_alignbyte(w2, w1, lead),
+                                           q2 = __builtin_amdgcn_alignbyte(w3, w2, lead);
+                            unsigned cr[4] = {q0 & 255u, q0 >> 24, (q1 >> 16) & 255u, (q2 >> 8) & 255u};
+                            unsigned cg[4] = {(q0 >> 8) & 255u, q1 & 255u, q1 >> 24, (q2 >> 16) & 255u};
+                            unsigned cb[4] = {(q0 >> 16) & 255u, (q1 >> 8) & 255u, q2 & 255u, q2 >> 24};
+                            if (MODE != SGCLIP_CROP_PLAIN) {
+                                const unsigned am = __builtin_amdgcn_alignbyte(ma32[xq + 1], ma32[xq], ml);
+                                unsigned bm = 0;
+                                if (MODE == SGCLIP_CROP_PAIR) bm = __builtin_amdgcn_alignbyte(mb32[xq + 1], mb32[xq], bo);
+#pragma unroll
+                                for (int i = 0; i < 4; i++) {
+                                    const bool red = ((am >> (8 * i)) & 255u) != 0;
+                                    if (MODE == SGCLIP_CROP_OBJECT) {
+                                        const unsigned base = red ? 256u : 0u;
+                                        cr[i] = lut8[base + cr[i]];
+                                        cg[i] = lut8[base + cg[i]];
+                                        cb[i] = lut8[base + cb[i]];
+                                    } else {
+                                        const bool blue = ((bm >> (8 * i)) & 255u) != 0;
+                                        const unsigned rest = (red | blue) ? 768u : 0u;   // 768: the identity table
+                                        cr[i] = lut8[(blue ? 512u : rest) + cr[i]];
+                                        cg[i] = lut8[rest + cg[i]];
+                                        cb[i] = lut8[(red ? 512u : rest) + cb[i]];
+                                    }
+                                }
+                            }
+                            p0[xq] = (cr[0] | (cr[1] << 8) | (cr[2] << 16) | (cr[3] << 24)) ^ 0x80808080u;
+                            p1[xq] = (cg[0] | (cg[1] << 8) | (cg[2] << 16) | (cg[3] << 24)) ^ 0x80808080u;
+                            p2[xq] = (cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24)) ^ 0x80808080u;
+                        }
+                    };
+                    if (mode == SGCLIP_CROP_PAIR)
+                        blend(std::integral_constant<int, SGCLIP_CROP_PAIR>{});
+                    else if (mode == SGCLIP_CROP_OBJECT)
+                        blend(std::integral_constant<int, SGCLIP_CROP_OBJECT>{});
+                    else
+                        blend(std::integral_constant<int, SGCLIP_CROP_PLAIN>{});
+                }
+            }
+            __syncthreads();
+            // the raw bytes are consumed: refill them underneath C and D
+            if (cy + MR < ry1)
+                issue_chunk(cy + MR, ry1);
+            else if (bl + 1 < bpw)
+                issue_chunk(nry0, nry1);
+            // ---- C + D on this wave's column blocks
+            if (nb_mine > 0) {
+                // column-pass A operand: digits of the coefficients of output row fr for chunk rows 4 kg .. 4 kg + 3
+                unsigned av[3] = {0u, 0u, 0u};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int t = cy + 4 * kg + e - a_ym;
+                    const int cf = (t >= 0 && t < a_yn) ? kv[t * vrows + bl * BR + fr] : 0;
+                    int d0, d1, d2;
+                    byte_digits(cf, d0, d1, d2);
+                    av[0] |= (unsigned)(d0 & 255) << (8 * e);
+                    av[1] |= (unsigned)(d1 & 255) << (8 * e);
+                    av[2] |= (unsigned)(d2 & 255) << (8 * e);
+                }
+                const v4i av0 = {(int)av[0], 0, 0, 0}, av1 = {(int)av[1], 0, 0, 0}, av2 = {(int)av[2], 0, 0, 0};
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+#pragma unroll
+                    for (int nbi = 0; nbi < NBW; nbi++) {
+                        if (nbi >= nb_mine) continue;
+                        const uint8_t *prow = planes + (ch * MR + fr) * PST + x0[nbi] + 16 * kg;
+                        v4i s0 = {hstart[nbi], hstart[nbi], hstart[nbi], hstart[nbi]}, s1 = zero4, s2 = zero4;
+#pragma unroll
+                        for (int kb = 0; kb < MKB; kb++) {
+                            const v4i px = *(const v4i *)(prow + 64 * kb);
+                            s0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(px, bco[nbi][kb][0], s0, 0, 0, 0);
+                            s1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(px, bco[nbi][kb][1], s1, 0, 0, 0);
+                            s2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(px, bco[nbi][kb][2], s2, 0, 0, 0);
+                        }
+                        // (each level goes through an opaque move: left to itself the compiler packs two of them with
+                        // v_ashr_pk_u8_i32, which leaves the upper half of its destination as it was -- stale bits
+                        // that would land in the byte of row 3)
+                        unsigned hp = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            int level = clip8(s0[e] + (s1[e] << 8) + (s2[e] << 16));
+                            asm volatile("" : "+v"(level));
+                            hp |= (unsigned)level << (8 * e);
+                        }
+                        const v4i hb = {(int)(hp ^ 0x80808080u), 0, 0, 0};
+                        const v4i t0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av0, hb, zero4, 0, 0, 0);
+                        const v4i t1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av1, hb, zero4, 0, 0, 0);
+                        const v4i t2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av2, hb, zero4, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) vsum[ch][nbi][e] += t0[e] + (t1[e] << 8) + (t2[e] << 16);
+                    }
+                }
+            }
+        }
+        ry0 = nry0;
+        ry1 = nry1;
+
+        // ---- output of this band: lane = column 16 nb + fr, rows 4 kg + e
+        if (wide) {
+            bf16_t *stage = (bf16_t *)(smem + L.planes);
+            __syncthreads();   // every wave is done with the planes
+#pragma unroll
+            for (int nbi = 0; nbi < NBW; nbi++) {
+                const int col = 16 * (wave * NBW + nbi) + fr;
+                if (nbi < nb_mine && col < S) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            stage[((4 * kg + e) * 3 + ch) * S + col] = (bf16_t)norm[ch * 256 + clip8(vsum[ch][nbi][e])];
+                }
+            }
+            __syncthreads();
+            const int per_row = S >> 3;
+            for (int v = tid; v < BR * 3 * per_row; v += NTM) {
+                const int line = v / per_row, col = (v - line * per_row) << 3;
+                const int rr = line / 3, ch = line - rr * 3;
+                const int oy = band * BR + rr;
+                size_t o;
+                if (patches) {
+                    const size_t prow = (size_t)crop_i * G * G + (size_t)(oy / patch) * G + col / patch;
+                    o = prow * a.kpad + (size_t)ch * patch * patch + (oy % patch) * patch + col % patch;
+                } else {
+                    o = (((size_t)crop_i * 3 + ch) * S + oy) * S + col;
+                }
+                *(uint4 *)((bf16_t *)a.out + o) = *(const uint4 *)(stage + line * S + col);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int nbi = 0; nbi < NBW; nbi++) {
+            const int col = 16 * (wave * NBW + nbi) + fr;
+            if (nbi < nb_mine && col < S) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int oy = band * BR + 4 * kg + e;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float v = norm[ch * 256 + clip8(vsum[ch][nbi][e])];
+                        size_t o;
+                        if (patches) {
+                            const size_t prow = (size_t)crop_i * G * G + (size_t)(oy / patch) * G + col / patch;
+                            o = prow * a.kpad + (size_t)ch * patch * patch + (oy % patch) * patch + col % patch;
+                        } else {
+                            o = (((size_t)crop_i * 3 + ch) * S + oy) * S + col;
+                        }
+                        if (a.out_dtype == SGCLIP_DTYPE_BF16)
+                            ((bf16_t *)a.out)[o] = (bf16_t)v;
+                        else
+                            ((float *)a.out)[o] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace sgclip
 
 using namespace sgclip;
@@ -603,11 +1050,21 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
     // occupancy classes by LDS need: 4 / 3 / 2 / 1 workgroups per CU; class 4 = crops whose whole visible source span
     // does not fit even with one band per workgroup: they run over column segments
     static const int class_hi[4] = {40 * 1024, 53 * 1024, 80 * 1024, LDS_LIMIT};
+    // the matrix-core kernel's classes: two workgroups per CU (its registers allow no more), or one
+    static const int mclass_hi[2] = {80 * 1024, LDS_LIMIT};
+    static int use_mfma_env = -1;
+    if (use_mfma_env < 0) {
+        const char *e = getenv("SGCLIP_CROP_MFMA");
+        use_mfma_env = e ? atoi(e) : 1;
+    }
+    bool use_mfma = use_mfma_env != 0;
     int ksx[5], ksy[5], wnc[5], members[5];
+    int mksx[2], mksy[2], mwnc[2], mmembers[2];
     double algo_bytes = 0;  // per crop: 3hw frame + m*hw mask + out
     for (;;) {
         bool too_big = false;
         for (int k = 0; k < 5; k++) ksx[k] = ksy[k] = wnc[k] = 1, members[k] = 0;
+        for (int k = 0; k < 2; k++) mksx[k] = mksy[k] = mwnc[k] = 1, mmembers[k] = 0;
         algo_bytes = 0;
         for (int i = 0; i < n_crops; i++) {
             const sgclip_crop_t &c = crops[i];
@@ -639,6 +1096,14 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
             int x0, n0, x1, n1;
             axis_bounds(w, new_w, left, x0, n0);
             axis_bounds(w, new_w, left + S - 1, x1, n1);
+            if (use_mfma && crop_mfma_ok(w, h, S, bpw * BR)) {
+                const int km = crop_need_m(w, h, S, bpw * BR) > mclass_hi[0] ? 1 : 0;
+                mksx[km] = std::max(mksx[km], axis_ksize(w, new_w));
+                mksy[km] = std::max(mksy[km], axis_ksize(h, new_h));
+                mwnc[km] = std::max(mwnc[km], x1 + n1 - x0);
+                mmembers[km]++;
+                continue;
+            }
             const int need = crop_need(w, h, S, bpw * BR);
             int k = 0;
             if (need > LDS_LIMIT) {
@@ -660,12 +1125,20 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
             for (int k = 0; k < 4; k++)
                 if (members[k] && crop_lds(S, ksx[k], ksy[k], wnc[k], bpw * BR).total > LDS_LIMIT) too_big = true;
         }
-        if (!too_big) break;
-        if (bpw == 1) {
-            set_error("sgclip_crop_preprocess: an LDS class exceeds %d bytes", LDS_LIMIT);
-            return SGCLIP_EINVAL;
+        bool m_too_big = false;
+        for (int k = 0; k < 2; k++)
+            if (mmembers[k] && crop_lds_m(S, mksx[k], mksy[k], mwnc[k], bpw * BR).total > LDS_LIMIT) m_too_big = true;
+        if (!too_big && !m_too_big) break;
+        if (bpw > 1) {
+            bpw = 1;  // per-band coefficient tables are the smallest layout
+            continue;
         }
-        bpw = 1;  // per-band coefficient tables are the smallest layout
+        if (m_too_big && use_mfma) {
+            use_mfma = false;   // shared class capacities beyond the LDS: everything on the vector kernel
+            continue;
+        }
+        set_error("sgclip_crop_preprocess: an LDS class exceeds %d bytes", LDS_LIMIT);
+        return SGCLIP_EINVAL;
     }
     // segmented class: the fewest column segments whose widest source span fits the LDS
     int nseg = 1;
@@ -675,7 +1148,7 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
             for (int i = 0; i < n_crops; i++) {
                 const sgclip_crop_t &c = crops[i];
                 const int w = c.x2 - c.x1, h = c.y2 - c.y1;
-                if (crop_need(w, h, S, BR) <= LDS_LIMIT) continue;
+                if ((use_mfma && crop_mfma_ok(w, h, S, BR)) || crop_need(w, h, S, BR) <= LDS_LIMIT) continue;
                 int new_w, new_h, top, left;
                 crop_geom(w, h, S, new_w, new_h, top, left);
                 for (int sg = 0; sg < nseg; sg++) {
@@ -721,6 +1194,22 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
     const dim3 grid((unsigned)n_crops * (nbands / bpw)), block(NT);
     KernelTimer timer(TK_CROP, algo_bytes, stream);
     a.nseg = 1;
+    a.mfma_split = use_mfma ? 1 : 0;
+    for (int k = 0; k < 2 && use_mfma; k++) {
+        if (!mmembers[k]) continue;
+        a.ksx_cap = mksx[k];
+        a.ksy_cap = mksy[k];
+        a.wn_cap = mwnc[k];
+        a.need_lo = k ? mclass_hi[k - 1] : 0;
+        a.need_hi = mclass_hi[k];
+        const int lds_bytes = crop_lds_m(S, mksx[k], mksy[k], mwnc[k], bpw * BR).total;
+        auto go = [&](auto kernel) {
+            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+            hipLaunchKernelGGL(kernel, grid, dim3(NTM), lds_bytes, stream, a);
+        };
+        const int blocks = (S + 15) / 16;
+        if (blocks <= 8) go(crop_mfma_kernel<1>); else if (blocks <= 16) go(crop_mfma_kernel<2>); else go(crop_mfma_kernel<3>);
+    }
     for (int k = 0; k < 5; k++) {
         if (!members[k]) continue;
         a.ksx_cap = ksx[k];

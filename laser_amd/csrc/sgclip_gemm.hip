@@ -44,6 +44,7 @@ struct GemmArgs {
     int wide_epilogue;  // N % 8 == 0, ldc % 8 == 0 and C, bias, aux 16-byte aligned
     int debug_mode;     // diagnostics only: 1 = skip epilogue stores, 2 = single K step
     float *colsum;      // EPI_MULGRAD through epilogue_passes: += column sums of C (null: none)
+    int col_group;      // gemm_pipe64_kernel: tiles walk down the rows inside groups of this many tile columns (0: row major)
     int tn_gm, tn_gn, tn_upx;   // gemm_tn_kernel: tile group shape and (group, slice) units per XCD (tn_gm = 0: plain grid)
 };
 
@@ -727,7 +728,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 rows x 128 columns
     const int swz = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = swz / g.tiles_n, tn = swz - tm * g.tiles_n;
+    // An XCD works through a contiguous run of the tile sequence, 32 tiles at a time.  Row major, a wide N puts all of W
+    // under every round; when W is larger than the XCD's L2 it is then fetched again every round.  Inside a group of
+    // col_group tile columns the run walks down the rows instead, and the group's W panels stay in the L2.
+    int tm, tn;
+    if (g.col_group) {
+        const int per = g.tiles_m * g.col_group;
+        const int cg = swz / per, r = swz - cg * per;
+        const int width = min(g.col_group, g.tiles_n - cg * g.col_group);
+        tm = r / width;
+        tn = cg * g.col_group + (r - tm * width);
+    } else {
+        tm = swz / g.tiles_n;
+        tn = swz - tm * g.tiles_n;
+    }
     const int m0 = tm * 256, n0 = tn * 256;
     const int frow = lane & 15, fq = lane >> 4;
 
@@ -1111,6 +1125,26 @@ static bool runs_on_pipe64(int M, int N, int K, int k_shortest, int splits) {
     return gemm_variant() >= 7 && big_tiles >= pipe64_min_tiles() && M > 128 && K % 64 == 0 && k_shortest >= 128 && N >= 256;
 }
 
+// Tile columns per group for gemm_pipe64_kernel's tile order (0: row major), from the bytes the 8 L2s would fetch:
+// row major reads A once and, when W does not fit an L2 beside the streams, W's panels once per round of 256 tiles;
+// grouped reads A once per group and each group's panels (which fit) once per XCD.
+static int pipe64_col_group(int tiles_m, int tiles_n, int K) {
+    static int env = -2;
+    if (env == -2) {
+        const char *e = getenv("SGCLIP_COL_GROUP");
+        env = e ? atoi(e) : -1;
+    }
+    if (env >= 0) return env >= tiles_n ? 0 : env;
+    const double panel = 256.0 * K * 2, l2_room = 2.5e6;
+    const double a_bytes = panel * tiles_m, rounds = (double)tiles_m * tiles_n / 256.0;
+    if (panel * tiles_n <= l2_room || rounds < 2) return 0;
+    const double row_major = a_bytes + rounds * 8 * std::min(tiles_n, 32) * panel;
+    const int gn = (int)(l2_room / panel);
+    if (gn < 1) return 0;
+    const double grouped = a_bytes * ceil_div(tiles_n, gn) + 8.0 * panel * tiles_n;
+    return grouped < 0.8 * row_major ? gn : 0;
+}
+
 static thread_local float *g_mulgrad_colsum = nullptr;   // set around its call by sgclip_gemm_mulgelugrad_bf16
 
 template <int EPI>
@@ -1127,6 +1161,7 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
     if (runs_on_pipe64(g.M, g.N, g.K, k_shortest, splits)) {
         g.tiles_m = ceil_div(g.M, 256);
         g.tiles_n = ceil_div(g.N, 256);
+        g.col_group = splits == 1 ? pipe64_col_group(g.tiles_m, g.tiles_n, g.K) : 0;
         auto go = [&](auto kernel) {
             lds_attr_once((const void *)kernel, 2 * P64_SLOT);
             hipLaunchKernelGGL(kernel, dim3((unsigned)g.tiles_m * g.tiles_n, gy), dim3(512), 2 * P64_SLOT, stream, g);
@@ -1199,6 +1234,7 @@ extern "C" int sgclip_gemm_bf16(const void *A_dev, int lda, const void *W_dev, i
         return SGCLIP_EINVAL;
     }
     GemmArgs g;
+    memset(&g, 0, sizeof(g));
     g.A = (const bf16_t *)A_dev;
     g.W = (const bf16_t *)W_dev;
     g.C = C_dev;

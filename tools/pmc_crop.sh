@@ -11,7 +11,7 @@ import csv, glob, collections
 agg = collections.defaultdict(float)
 for fn in glob.glob("$R/gpurun_out/pmc_crop_$tag/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        if "crop_kernel" in r["Kernel_Name"]:
+        if "crop_" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
 for k, v in agg.items(): print(k, "%.4g" % v)
 PY
