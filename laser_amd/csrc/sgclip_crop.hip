@@ -646,6 +646,18 @@ __device__ __forceinline__ void byte_digits(int c, int &d0, int &d1, int &d2) {
     d2 = (c1 - d1) >> 8;
 }
 
+// bytes 0..3 = clip8(v0) .. clip8(v3).  v_ashr_pk_u8_i32 shifts two values, saturates them to bytes and writes HALF of
+// its destination (op_sel picks the high half); the other half keeps the register's old bits (tools/micro/ashr_pk.hip).
+// The compiler forms the low-half instruction by itself from shift + clamp + pack code and then treats the stale upper
+// half as zero, so such code must not be left to it where the upper bytes matter.
+__device__ __forceinline__ unsigned pack_levels(int v0, int v1, int v2, int v3) {
+    unsigned d;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 22" : "=v"(d) : "v"(v0), "v"(v1));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, 22 op_sel:[0,0,0,1]" : "+v"(d) : "v"(v2), "v"(v3));
+    return d;
+}
+static_assert(PREC == 22, "pack_levels shifts by the literal 22");
+
 template <int NBW>
 __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -917,22 +929,15 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
                             s1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(px, bco[nbi][kb][1], s1, 0, 0, 0);
                             s2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(px, bco[nbi][kb][2], s2, 0, 0, 0);
                         }
-                        // (each level goes through an opaque move: left to itself the compiler packs two of them with
-                        // v_ashr_pk_u8_i32, which leaves the upper half of its destination as it was -- stale bits
-                        // that would land in the byte of row 3)
-                        unsigned hp = 0;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            int level = clip8(s0[e] + (s1[e] << 8) + (s2[e] << 16));
-                            asm volatile("" : "+v"(level));
-                            hp |= (unsigned)level << (8 * e);
-                        }
+                        // digits recombined Horner fashion: two shift-adds per value
+                        const unsigned hp = pack_levels((((s2[0] << 8) + s1[0]) << 8) + s0[0], (((s2[1] << 8) + s1[1]) << 8) + s0[1],
+                                                        (((s2[2] << 8) + s1[2]) << 8) + s0[2], (((s2[3] << 8) + s1[3]) << 8) + s0[3]);
                         const v4i hb = {(int)(hp ^ 0x80808080u), 0, 0, 0};
                         const v4i t0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av0, hb, zero4, 0, 0, 0);
                         const v4i t1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av1, hb, zero4, 0, 0, 0);
                         const v4i t2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(av2, hb, zero4, 0, 0, 0);
 #pragma unroll
-                        for (int e = 0; e < 4; e++) vsum[ch][nbi][e] += t0[e] + (t1[e] << 8) + (t2[e] << 16);
+                        for (int e = 0; e < 4; e++) vsum[ch][nbi][e] += (((t2[e] << 8) + t1[e]) << 8) + t0[e];
                     }
                 }
             }
