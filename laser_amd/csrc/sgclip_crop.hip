@@ -249,6 +249,17 @@ __host__ __device__ inline bool crop_mfma_ok(int w, int h, int S, int vrows) {
     return crop_need_m(w, h, S, vrows) <= LDS_LIMIT;
 }
 
+// 64-pixel windows the crop's column blocks need by the same bound: 1 up to a scale of about 2.4 (three quarters of
+// the pair crops of a 720p clip), else 2.  The one-window kernel holds half the coefficient operands (no spills with two
+// column blocks per wave) and issues half the row-pass MFMAs.
+__host__ __device__ inline int crop_mfma_windows(int w, int h, int S) {
+#pragma clang fp contract(off)
+    int new_w, new_h, top, left;
+    crop_geom(w, h, S, new_w, new_h, top, left);
+    const double scale = (double)w / new_w;
+    return 15.0 * scale + axis_ksize(w, new_w) + 17.0 <= 64.0 ? 1 : 2;
+}
+
 __device__ __forceinline__ int clip8(int v) {
     v >>= PREC;
     return v < 0 ? 0 : (v > 255 ? 255 : v);
@@ -658,8 +669,11 @@ __device__ __forceinline__ unsigned pack_levels(int v0, int v1, int v2, int v3) 
 }
 static_assert(PREC == 22, "pack_levels shifts by the literal 22");
 
-template <int NBW>
-__global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropArgs a) {
+// (two-window crops have spans beyond ~540 pixels: their staging leaves room for one workgroup per CU anyway, so that
+// kernel may use the registers of two: with 128 it spills coefficient operands, and every reload in the chunk loop
+// waits for the row prefetch as well)
+template <int NBW, int KB>
+__global__ __launch_bounds__(NTM, (NBW <= 2 && KB == 1) ? 4 : 2) void crop_mfma_kernel(CropArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -671,7 +685,7 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
     const sgclip_crop_t c = a.crops[crop_i];
     const int S = a.S;
     const int w = c.x2 - c.x1, h = c.y2 - c.y1;
-    if (!crop_mfma_ok(w, h, S, vrows)) return;
+    if (!crop_mfma_ok(w, h, S, vrows) || crop_mfma_windows(w, h, S) != KB) return;
     {
         const int need = crop_need_m(w, h, S, vrows);
         if (need <= a.need_lo || need > a.need_hi) return;
@@ -725,7 +739,7 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
         const int cl = min(16 * nb + 15, S - 1);
         const int lo = (__builtin_amdgcn_readfirstlane(xmin[16 * nb]) - cx0) & ~15;
         const int hi = __builtin_amdgcn_readfirstlane(xmin[cl] + xcnt[cl]) - cx0;
-        fits = fits && hi - lo <= 64 * MKB;
+        fits = fits && hi - lo <= 64 * KB;
     }
     if (!fits) return;   // host sizing and crop_mfma_ok guarantee this never triggers
 
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
     const int fr = lane & 15, kg = lane >> 4;
     const int nb_mine = max(0, min(NBW, nblocks - wave * NBW));
     int x0[NBW], hstart[NBW];
-    v4i bco[NBW][MKB][3];
+    v4i bco[NBW][KB][3];
 #pragma unroll
     for (int nbi = 0; nbi < NBW; nbi++) {
         const int nb = min(wave * NBW + nbi, nblocks - 1);
@@ -746,7 +760,7 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
         for (int t = 0; t < n; t++) ksum += kh[t * S + col];
         hstart[nbi] = (1 << (PREC - 1)) + 128 * ksum;
 #pragma unroll
-        for (int kb = 0; kb < MKB; kb++) {
+        for (int kb = 0; kb < KB; kb++) {
             unsigned pk[3][4];
 #pragma unroll
             for (int q = 0; q < 4; q++) pk[0][q] = pk[1][q] = pk[2][q] = 0u;
@@ -810,6 +824,7 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
         // this lane's output rows in the column pass: 4 kg + e; its A-operand row there: fr
         v4i vsum[3][NBW];
         {
+            const int kg = fresh(lane) >> 4;
             int vstart[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -838,7 +853,10 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
             // byte offset), every channel goes through exactly one table read -- the identity table where the
             // reference leaves the level alone -- and nothing branches per pixel.
             {
-                const int r = tid >> 5;
+                // (thread indices through fresh(): addresses derived from them are recomputed here instead of living in
+                // registers across the kernel, where they push the coefficient operands into scratch)
+                const int bt = fresh(tid);
+                const int r = bt >> 5;
                 if (r < nrows) {
                     const size_t pix0 = (size_t)(c.y1 + cy + r) * c.frame_w + (c.x1 + cx0);
                     const unsigned lead = (unsigned)((uintptr_t)(fbase + pix0 * 3) & 3);
@@ -852,7 +870,7 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
                     const int nq = (wn + 3) >> 2;
                     auto blend = [&](auto mode_c) {
                         constexpr int MODE = decltype(mode_c)::value;
-                        for (int xq = tid & 31; xq < nq; xq += 32) {
+                        for (int xq = bt & 31; xq < nq; xq += 32) {
                             const unsigned w0 = raw32[3 * xq], w1 = raw32[3 * xq + 1], w2 = raw32[3 * xq + 2], w3 = raw32[3 * xq + 3];
                             // bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
                             const unsigned q0 = __builtin_amdgcn_alignbyte(w1, w0, lead), q1 = __builtin_amdgcn_alignbyte(w2, w1, lead),
@@ -902,6 +920,8 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
                 issue_chunk(nry0, nry1);
             // ---- C + D on this wave's column blocks
             if (nb_mine > 0) {
+                const int cl_lane = fresh(lane);
+                const int fr = cl_lane & 15, kg = cl_lane >> 4;
                 // column-pass A operand: digits of the coefficients of output row fr for chunk rows 4 kg .. 4 kg + 3
                 unsigned av[3] = {0u, 0u, 0u};
 #pragma unroll
@@ -923,7 +943,7 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
                         const uint8_t *prow = planes + (ch * MR + fr) * PST + x0[nbi] + 16 * kg;
                         v4i s0 = {hstart[nbi], hstart[nbi], hstart[nbi], hstart[nbi]}, s1 = zero4, s2 = zero4;
 #pragma unroll
-                        for (int kb = 0; kb < MKB; kb++) {
+                        for (int kb = 0; kb < KB; kb++) {
                             const v4i px = *(const v4i *)(prow + 64 * kb);
                             s0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(px, bco[nbi][kb][0], s0, 0, 0, 0);
                             s1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(px, bco[nbi][kb][1], s1, 0, 0, 0);
@@ -946,6 +966,8 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
         ry1 = nry1;
 
         // ---- output of this band: lane = column 16 nb + fr, rows 4 kg + e
+        const int ol = fresh(lane);
+        const int fr = ol & 15, kg = ol >> 4;
         if (wide) {
             bf16_t *stage = (bf16_t *)(smem + L.planes);
             __syncthreads();   // every wave is done with the planes
@@ -962,7 +984,7 @@ __global__ __launch_bounds__(NTM, NBW <= 2 ? 4 : 2) void crop_mfma_kernel(CropAr
             }
             __syncthreads();
             const int per_row = S >> 3;
-            for (int v = tid; v < BR * 3 * per_row; v += NTM) {
+            for (int v = fresh(tid); v < BR * 3 * per_row; v += NTM) {
                 const int line = v / per_row, col = (v - line * per_row) << 3;
                 const int rr = line / 3, ch = line - rr * 3;
                 const int oy = band * BR + rr;
@@ -1064,12 +1086,12 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
     }
     bool use_mfma = use_mfma_env != 0;
     int ksx[5], ksy[5], wnc[5], members[5];
-    int mksx[2], mksy[2], mwnc[2], mmembers[2];
+    int mksx[2], mksy[2], mwnc[2], mmembers[2], mwin[2][2];   // mwin[class][windows - 1]: members by window count
     double algo_bytes = 0;  // per crop: 3hw frame + m*hw mask + out
     for (;;) {
         bool too_big = false;
         for (int k = 0; k < 5; k++) ksx[k] = ksy[k] = wnc[k] = 1, members[k] = 0;
-        for (int k = 0; k < 2; k++) mksx[k] = mksy[k] = mwnc[k] = 1, mmembers[k] = 0;
+        for (int k = 0; k < 2; k++) mksx[k] = mksy[k] = mwnc[k] = 1, mmembers[k] = mwin[k][0] = mwin[k][1] = 0;
         algo_bytes = 0;
         for (int i = 0; i < n_crops; i++) {
             const sgclip_crop_t &c = crops[i];
@@ -1107,6 +1129,7 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
                 mksy[km] = std::max(mksy[km], axis_ksize(h, new_h));
                 mwnc[km] = std::max(mwnc[km], x1 + n1 - x0);
                 mmembers[km]++;
+                mwin[km][crop_mfma_windows(w, h, S) - 1]++;
                 continue;
             }
             const int need = crop_need(w, h, S, bpw * BR);
@@ -1213,7 +1236,12 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
             hipLaunchKernelGGL(kernel, grid, dim3(NTM), lds_bytes, stream, a);
         };
         const int blocks = (S + 15) / 16;
-        if (blocks <= 8) go(crop_mfma_kernel<1>); else if (blocks <= 16) go(crop_mfma_kernel<2>); else go(crop_mfma_kernel<3>);
+        if (mwin[k][0]) {
+            if (blocks <= 8) go(crop_mfma_kernel<1, 1>); else if (blocks <= 16) go(crop_mfma_kernel<2, 1>); else go(crop_mfma_kernel<3, 1>);
+        }
+        if (mwin[k][1]) {
+            if (blocks <= 8) go(crop_mfma_kernel<1, 2>); else if (blocks <= 16) go(crop_mfma_kernel<2, 2>); else go(crop_mfma_kernel<3, 2>);
+        }
     }
     for (int k = 0; k < 5; k++) {
         if (!members[k]) continue;
