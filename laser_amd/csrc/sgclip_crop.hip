@@ -778,6 +778,8 @@ __global__ __launch_bounds__(NTM, (NBW <= 2 && KB == 1) ? 4 : 2) void crop_mfma_
             for (int d = 0; d < 3; d++) bco[nbi][kb][d] = (v4i){(int)pk[d][0], (int)pk[d][1], (int)pk[d][2], (int)pk[d][3]};
         }
     }
+    // the blend pass wants level - 128: fold that into the tables (the DMA that brought them in was waited for above)
+    if (tid < 256) ((unsigned *)lut8)[tid] ^= 0x80808080u;
     __syncthreads();   // the coefficient table is dead from here on: its bytes become the planes
 
     const int mode = c.mode;
@@ -875,33 +877,45 @@ __global__ __launch_bounds__(NTM, (NBW <= 2 && KB == 1) ? 4 : 2) void crop_mfma_
                             // bytes R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
                             const unsigned q0 = __builtin_amdgcn_alignbyte(w1, w0, lead), q1 = __builtin_amdgcn_alignbyte(w2, w1, lead),
                                            q2 = __builtin_amdgcn_alignbyte(w3, w2, lead);
-                            unsigned cr[4] = {q0 & 255u, q0 >> 24, (q1 >> 16) & 255u, (q2 >> 8) & 255u};
-                            unsigned cg[4] = {(q0 >> 8) & 255u, q1 & 255u, q1 >> 24, (q2 >> 16) & 255u};
-                            unsigned cb[4] = {(q0 >> 16) & 255u, (q1 >> 8) & 255u, q2 & 255u, q2 >> 24};
-                            if (MODE != SGCLIP_CROP_PLAIN) {
-                                const unsigned am = __builtin_amdgcn_alignbyte(ma32[xq + 1], ma32[xq], ml);
-                                unsigned bm = 0;
-                                if (MODE == SGCLIP_CROP_PAIR) bm = __builtin_amdgcn_alignbyte(mb32[xq + 1], mb32[xq], bo);
+                            // v_perm_b32 picks result bytes from {hi, lo}: selector byte 0-3 = lo's bytes, 4-7 = hi's, 0x0c = zero
+                            if (MODE == SGCLIP_CROP_PLAIN) {
+                                const unsigned tr = __builtin_amdgcn_perm(q1, q0, 0x0c060300u), tg = __builtin_amdgcn_perm(q1, q0, 0x0c070401u),
+                                               tb = __builtin_amdgcn_perm(q1, q0, 0x0c0c0502u);
+                                p0[xq] = __builtin_amdgcn_perm(q2, tr, 0x05020100u) ^ 0x80808080u;
+                                p1[xq] = __builtin_amdgcn_perm(q2, tg, 0x06020100u) ^ 0x80808080u;
+                                p2[xq] = __builtin_amdgcn_perm(q2, tb, 0x07040100u) ^ 0x80808080u;
+                                continue;
+                            }
+                            // Table number of every pixel and channel as packed bytes (0, 1: the object's two tables; pair:
+                            // 0 outside both masks, 2 for the channel its mask colours, 3 = identity for the others), then
+                            // one v_perm per lookup builds the address (table << 8) | level.  The tables hold level - 128
+                            // already (see the setup), so the packed results are the plane bytes.
+                            auto nonzero_bytes = [](unsigned x) { return ((((x | 0x80808080u) - 0x01010101u) | x) >> 7) & 0x01010101u; };
+                            const unsigned a1 = nonzero_bytes(__builtin_amdgcn_alignbyte(ma32[xq + 1], ma32[xq], ml));
+                            unsigned t4[3] = {a1, a1, a1};
+                            if (MODE == SGCLIP_CROP_PAIR) {
+                                const unsigned b1 = nonzero_bytes(__builtin_amdgcn_alignbyte(mb32[xq + 1], mb32[xq], bo));
+                                const unsigned any3 = (a1 | b1) * 3u;
+                                t4[0] = any3 - b1;
+                                t4[1] = any3;
+                                t4[2] = any3 - a1;
+                            }
+                            const unsigned qw[3] = {q0, q1, q2};
+                            unsigned o[3];
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++) {
+                                unsigned lv[4];
 #pragma unroll
                                 for (int i = 0; i < 4; i++) {
-                                    const bool red = ((am >> (8 * i)) & 255u) != 0;
-                                    if (MODE == SGCLIP_CROP_OBJECT) {
-                                        const unsigned base = red ? 256u : 0u;
-                                        cr[i] = lut8[base + cr[i]];
-                                        cg[i] = lut8[base + cg[i]];
-                                        cb[i] = lut8[base + cb[i]];
-                                    } else {
-                                        const bool blue = ((bm >> (8 * i)) & 255u) != 0;
-                                        const unsigned rest = (red | blue) ? 768u : 0u;   // 768: the identity table
-                                        cr[i] = lut8[(blue ? 512u : rest) + cr[i]];
-                                        cg[i] = lut8[rest + cg[i]];
-                                        cb[i] = lut8[(red ? 512u : rest) + cb[i]];
-                                    }
+                                    constexpr unsigned ZZ = 0x0c0c0000u;
+                                    const int lin = 3 * i + ch;   // byte of the 12-byte item
+                                    lv[i] = lut8[__builtin_amdgcn_perm(t4[ch], qw[lin >> 2], ZZ | ((4u + i) << 8) | (unsigned)(lin & 3))];
                                 }
+                                o[ch] = lv[0] | (lv[1] << 8) | (lv[2] << 16) | (lv[3] << 24);
                             }
-                            p0[xq] = (cr[0] | (cr[1] << 8) | (cr[2] << 16) | (cr[3] << 24)) ^ 0x80808080u;
-                            p1[xq] = (cg[0] | (cg[1] << 8) | (cg[2] << 16) | (cg[3] << 24)) ^ 0x80808080u;
-                            p2[xq] = (cb[0] | (cb[1] << 8) | (cb[2] << 16) | (cb[3] << 24)) ^ 0x80808080u;
+                            p0[xq] = o[0];
+                            p1[xq] = o[1];
+                            p2[xq] = o[2];
                         }
                     };
                     if (mode == SGCLIP_CROP_PAIR)
