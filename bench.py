@@ -215,6 +215,19 @@ def pmc_traffic(substr):
     return tot / n if n else None
 
 
+def pmc_traffic_per_call(substrs, calls_per_step):
+    """HBM bytes per library call for a call that launches several kernels (the crop call: one launch per class and
+    kernel variant): the bytes of all kernels whose name contains one of `substrs` in the newest PMC file, divided
+    by the passes that profile made over the step and by the calls one step makes.  None without such a file."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_traffic.json")))
+    if not found or not calls_per_step:
+        return None
+    d = json.load(open(found[-1]))
+    tot = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for k, v in d["kernels"].items() if any(s in k for s in substrs))
+    return tot / d.get("passes", 3) / calls_per_step if tot else None
+
+
 def timing_read(kind):
     lib = _lib.load()
     ms, n, work = C.c_double(), C.c_int64(), C.c_double()
@@ -494,8 +507,11 @@ def main():
                      "note": "launch durations from HIP events in a pass that queues the towers on ONE stream, so an "
                              "event pair brackets its kernel alone (rocprof summary of that mode: BENCH_STREAMS=0); the "
                              "timed steps behind `value` overlap the towers on four streams"},
-        "roofline_crop": {"kernel": "sgclip::crop_kernel", "bound": "hbm", "achieved": crop_gbs, "peak": HBM_PEAK_GBS,
-                          "unit": "GB/s", "frac": crop_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("crop_kernel"),
+        "roofline_crop": {"kernel": "sgclip::crop_mfma_kernel (+ sgclip::crop_kernel for the crops it does not take), per "
+                                    "sgclip_crop_preprocess call",
+                          "bound": "hbm", "achieved": crop_gbs, "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": crop_gbs / HBM_PEAK_GBS,
+                          "traffic": pmc_traffic_per_call(("crop_mfma_kernel", "crop_kernel"), crop_n / max(tsteps, 1)),
                           "algorithmic_bytes_per_launch": crop_bytes / max(crop_n, 1),
                           "avg_launch_ms": crop_ms / max(crop_n, 1), "algorithmic_bytes_per_step": plan.algo_crop_bytes},
         "kernel_ms_per_step": step_ms_timed,
