@@ -428,8 +428,35 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
     float csum[EPI == EPI_MULGRAD ? CPL : 1];   // this lane's columns summed over the rows it stores
 #pragma unroll
     for (int q = 0; q < (EPI == EPI_MULGRAD ? CPL : 1); q++) csum[q] = 0.f;
+    // Epilogues that read a second input (the residual stream, the position rows, the pre-activation) fetch a whole
+    // pass of it, 16 bytes per lane and row, one pass ahead of its use: issued next to its store, every fetch would
+    // wait out the memory latency on its own, 16 / RPI round trips per pass with one KiB in flight per wave.
+    constexpr bool SIDE = EPI == SGCLIP_EPI_BIAS_RESID_F32 || EPI == SGCLIP_EPI_PATCH_F32 || EPI == EPI_MULGRAD;
+    constexpr int NR = 16 / RPI;                   // store instructions per pass
+    float4 side[SIDE ? 2 : 1][SIDE ? NR : 1];
+    const int n_in = n < g.N ? n : 0;
+    auto side_fetch = [&](int i, float4 (&dst)[SIDE ? NR : 1]) {
+        if constexpr (SIDE) {
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                int m = mw + i * 16 + rr * RPI + rl;
+                m = m < g.M ? m : g.M - 1;
+                const void *src;
+                if constexpr (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
+                    src = (g.aux ? g.aux : (const float *)g.C) + (size_t)m * g.ldc + n_in;
+                } else if constexpr (EPI == SGCLIP_EPI_PATCH_F32) {
+                    src = g.aux + (size_t)(1 + m % g.aux_rows) * g.ldc + n_in;
+                } else {
+                    src = (const bf16_t *)g.aux + (size_t)m * g.ldc + n_in;
+                }
+                dst[rr] = *(const float4 *)src;
+            }
+        }
+    };
+    side_fetch(0, side[0]);
 #pragma unroll
     for (int i = 0; i < NI; i++) {
+        if (i + 1 < NI) side_fetch(i + 1, side[SIDE ? (i + 1) & 1 : 0]);
 #pragma unroll
         for (int j = 0; j < NJ; j++)
 #pragma unroll
@@ -437,8 +464,15 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
         // the region is private to this wave: its LDS writes only have to precede the reads of its
         // other lanes (a memory fence here would also wait for the previous pass's global stores)
         wave_lds_sync();
+        if (i == 0) {
+            // The bias must have arrived before the first bounds branch: a fetch still pending at a branch stays
+            // pending on the path around it, and from there on the compiler waits for vmcnt(0) in front of every
+            // use of it -- that is, for the previous global store's acknowledgement, 16 / RPI round trips per pass.
 #pragma unroll
-        for (int rr = 0; rr < 16 / RPI; rr++) {
+            for (int q = 0; q < CPL; q++) asm volatile("" : "+v"(bias[q]));
+        }
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
             const int row = rr * RPI + rl;
             const int m = mw + i * 16 + row;
             float v[CPL];
@@ -447,11 +481,12 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
                 const float4 t = *(const float4 *)(region + row * LDW + cl + q);
                 v[q] = t.x + bias[q]; v[q + 1] = t.y + bias[q + 1]; v[q + 2] = t.z + bias[q + 2]; v[q + 3] = t.w + bias[q + 3];
             }
+            [[maybe_unused]] const float4 sd = side[SIDE ? i & 1 : 0][SIDE ? rr : 0];
             if (m >= g.M || n >= g.N) continue;
             if constexpr (BF) {
                 bf16x8 o;
                 if constexpr (EPI == EPI_MULGRAD) {
-                    const bf16x8 u = *(const bf16x8 *)((const bf16_t *)g.aux + (size_t)m * g.ldc + n);
+                    const bf16x8 u = __builtin_bit_cast(bf16x8, sd);
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
                         o[q] = (bf16_t)(v[q] * quick_gelu_grad((float)u[q]));
@@ -469,15 +504,12 @@ __device__ __forceinline__ void epilogue_passes(const GemmArgs &g, const f32x4 (
                     *(bf16x8 *)((bf16_t *)g.aux + (size_t)m * g.ldc + n) = a;
                 }
             } else if constexpr (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
-                float4 *p = (float4 *)((float *)g.C + (size_t)m * g.ldc + n);
-                const float4 c = g.aux ? *(const float4 *)(g.aux + (size_t)m * g.ldc + n) : *p;
-                *p = make_float4(c.x + v[0], c.y + v[1], c.z + v[2], c.w + v[3]);
+                *(float4 *)((float *)g.C + (size_t)m * g.ldc + n) = make_float4(sd.x + v[0], sd.y + v[1], sd.z + v[2], sd.w + v[3]);
             } else if constexpr (EPI == SGCLIP_EPI_PATCH_F32) {
                 const int P = g.aux_rows;
                 const int img = m / P, pp = m - img * P;
                 const size_t orow = (size_t)img * (P + 1) + 1 + pp;
-                const float4 a = *(const float4 *)(g.aux + (size_t)(1 + pp) * g.ldc + n);
-                *(float4 *)((float *)g.C + orow * g.ldc + n) = make_float4(v[0] + a.x, v[1] + a.y, v[2] + a.z, v[3] + a.w);
+                *(float4 *)((float *)g.C + orow * g.ldc + n) = make_float4(v[0] + sd.x, v[1] + sd.y, v[2] + sd.z, v[3] + sd.w);
             } else if constexpr (EPI == SGCLIP_EPI_F32_ATOMIC) {
                 atomic_add4((float *)g.C + (size_t)m * g.ldc + n, v[0], v[1], v[2], v[3]);
             } else {
