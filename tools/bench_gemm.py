@@ -8,6 +8,7 @@ dev = torch.device("cuda:0")
 M = int(os.environ.get("M", 65536))
 shapes = [("qkv", 2304, 768, _lib.EPI_BIAS_BF16), ("oproj", 768, 768, _lib.EPI_BIAS_RESID_F32),
           ("fc1", 3072, 768, _lib.EPI_BIAS_GELU_BF16), ("fc1nogelu", 3072, 768, _lib.EPI_BIAS_BF16), ("fc2", 768, 3072, _lib.EPI_BIAS_RESID_F32),
+          ("oprojbf", 768, 768, _lib.EPI_BIAS_BF16), ("fc2bf", 768, 3072, _lib.EPI_BIAS_BF16),   # main-loop studies (debug modes)
           ("patch", 768, 3072, _lib.EPI_F32), ("sq4096", 4096, 4096, _lib.EPI_BIAS_BF16)]
 torch.manual_seed(0)
 only = os.environ.get("ONLY")
