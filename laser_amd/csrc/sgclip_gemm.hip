@@ -894,6 +894,302 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------
+// The same pipeline as a persistent kernel: one workgroup per CU walks through its share of the tiles, and the
+// operand stream never drains.  The last two stages of a tile already fetch the first two stages of the next one, so a
+// tile pays neither the workgroup turnaround (1-2 us) nor the latency of its first fetch (1.5-2 us), and the epilogue
+// needs no workgroup barrier: it is staged in 4 KiB per wave beyond the ring (8 rows x 128 columns of fp32, 16-column
+// groups XOR-swizzled by the lane quarter instead of padded rows), so no wave waits for the others to leave the ring.
+// ---------------------------------------------------------------------------
+constexpr int P64P_STAGE = 4096;                                  // epilogue staging bytes per wave
+constexpr int P64P_LDS = 2 * P64_SLOT + 8 * P64P_STAGE;           // 160 KiB
+
+// Eight-row epilogue passes of one wave's 64 x 128 block: pass (i, h) takes the rows 16 i + 4 fq + 2 h + {0, 1}.
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows8(const GemmArgs &g, const f32x4 (&acc)[4][8], float *region, int mw, int nw,
+                                               int lane) {
+    constexpr bool BF = epi_bf16_out<EPI>();
+    constexpr int CPL = BF ? 8 : 4;                // columns per lane
+    constexpr int LPR = 128 / CPL;                 // lanes per row
+    constexpr int RPI = 64 / LPR;                  // rows per store instruction
+    constexpr int NR = 8 / RPI;                    // store instructions per pass
+    constexpr int NP = 8;                          // passes
+    constexpr bool SIDE = EPI == SGCLIP_EPI_BIAS_RESID_F32 || EPI == SGCLIP_EPI_PATCH_F32 || EPI == EPI_MULGRAD;
+    constexpr int DEPTH = SIDE ? (BF ? 4 : 4) : 1; // passes of the second input in flight
+    const int frow = lane & 15, fq = lane >> 4;
+    const int cl = (lane % LPR) * CPL, rl = lane / LPR;
+    const int n = nw + cl;
+    const int n_in = n < g.N ? n : 0;
+    float bias[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; q++) bias[q] = 0.f;
+    if (epi_has_bias<EPI>() && n < g.N) {
+#pragma unroll
+        for (int q = 0; q < CPL; q += 4) {
+            const float4 b = *(const float4 *)(g.bias + n + q);
+            bias[q] = b.x; bias[q + 1] = b.y; bias[q + 2] = b.z; bias[q + 3] = b.w;
+        }
+    }
+    float csum[EPI == EPI_MULGRAD ? CPL : 1];
+#pragma unroll
+    for (int q = 0; q < (EPI == EPI_MULGRAD ? CPL : 1); q++) csum[q] = 0.f;
+    // local row lr of pass (i, h) is tile row 16 i + 4 (lr >> 1) + 2 h + (lr & 1)
+    auto tile_row = [&](int p, int lr) { return (p >> 1) * 16 + (lr >> 1) * 4 + (p & 1) * 2 + (lr & 1); };
+    float4 side[DEPTH][SIDE ? NR : 1];
+    auto side_fetch = [&](int p, float4 (&dst)[SIDE ? NR : 1]) {
+        if constexpr (SIDE) {
+#pragma unroll
+            for (int rr = 0; rr < NR; rr++) {
+                int m = mw + tile_row(p, rr * RPI + rl);
+                m = m < g.M ? m : g.M - 1;
+                const void *src;
+                if constexpr (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
+                    src = (g.aux ? g.aux : (const float *)g.C) + (size_t)m * g.ldc + n_in;
+                } else if constexpr (EPI == SGCLIP_EPI_PATCH_F32) {
+                    src = g.aux + (size_t)(1 + m % g.aux_rows) * g.ldc + n_in;
+                } else {
+                    src = (const bf16_t *)g.aux + (size_t)m * g.ldc + n_in;
+                }
+                dst[rr] = *(const float4 *)src;
+            }
+        }
+    };
+    if constexpr (SIDE) {
+#pragma unroll
+        for (int p = 0; p < DEPTH; p++) side_fetch(p, side[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const int i = p >> 1, h = p & 1;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) region[(fq * 2 + e) * 128 + ((j ^ fq) << 4) + frow] = acc[i][j][2 * h + e];
+        wave_lds_sync();
+        if (p == 0) {
+            // the bias must have arrived before the first bounds branch (a fetch pending at a branch stays pending on the
+            // path around it, and every later use then waits for vmcnt(0), i.e. for the previous store's acknowledgement)
+#pragma unroll
+            for (int q = 0; q < CPL; q++) asm volatile("" : "+v"(bias[q]));
+        }
+#pragma unroll
+        for (int rr = 0; rr < NR; rr++) {
+            const int lr = rr * RPI + rl;
+            const int m = mw + tile_row(p, lr);
+            float v[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; q += 4) {
+                const float4 t = *(const float4 *)(region + lr * 128 + ((cl + q) ^ ((lr >> 1) << 4)));
+                v[q] = t.x + bias[q]; v[q + 1] = t.y + bias[q + 1]; v[q + 2] = t.z + bias[q + 2]; v[q + 3] = t.w + bias[q + 3];
+            }
+            [[maybe_unused]] const float4 sd = side[SIDE ? p % DEPTH : 0][SIDE ? rr : 0];
+            if (m >= g.M || n >= g.N) continue;
+            if constexpr (BF) {
+                bf16x8 o;
+                if constexpr (EPI == EPI_MULGRAD) {
+                    const bf16x8 u = __builtin_bit_cast(bf16x8, sd);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        o[q] = (bf16_t)(v[q] * quick_gelu_grad((float)u[q]));
+                        csum[q] += (float)o[q];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) o[q] = (bf16_t)(EPI == SGCLIP_EPI_BIAS_GELU_BF16 ? quick_gelu(v[q]) : v[q]);
+                }
+                __builtin_nontemporal_store(o, (bf16x8 *)((bf16_t *)g.C + (size_t)m * g.ldc + n));
+                if constexpr (EPI == EPI_GELU_BOTH) {
+                    bf16x8 a;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) a[q] = (bf16_t)quick_gelu((float)o[q]);
+                    *(bf16x8 *)((bf16_t *)g.aux + (size_t)m * g.ldc + n) = a;
+                }
+            } else if constexpr (EPI == SGCLIP_EPI_BIAS_RESID_F32) {
+                *(float4 *)((float *)g.C + (size_t)m * g.ldc + n) = make_float4(sd.x + v[0], sd.y + v[1], sd.z + v[2], sd.w + v[3]);
+            } else if constexpr (EPI == SGCLIP_EPI_PATCH_F32) {
+                const int P = g.aux_rows;
+                const int img = m / P, pp = m - img * P;
+                const size_t orow = (size_t)img * (P + 1) + 1 + pp;
+                *(float4 *)((float *)g.C + orow * g.ldc + n) = make_float4(v[0] + sd.x, v[1] + sd.y, v[2] + sd.z, v[3] + sd.w);
+            } else {
+                *(float4 *)((float *)g.C + (size_t)m * g.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        if (p + DEPTH < NP) side_fetch(p + DEPTH, side[SIDE ? p % DEPTH : 0]);
+        wave_lds_sync();
+    }
+    if constexpr (EPI == EPI_MULGRAD) {
+        if (g.colsum) {
+#pragma unroll
+            for (int q = 0; q < CPL; q++) {
+#pragma unroll
+                for (int o = LPR; o < 64; o <<= 1) csum[q] += __shfl_xor(csum[q], o, 64);
+            }
+            if (rl == 0) {
+#pragma unroll
+                for (int q = 0; q < CPL; q++) region[cl + q] = csum[q];
+            }
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pipe64p_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 rows x 128 columns
+    const int frow = lane & 15, fq = lane >> 4;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    // virtual block index: the place this tile would have in a grid of one workgroup per tile (same XCD-aware order)
+    int vb = blockIdx.x;
+    int m0, n0;
+    auto tile_origin = [&](int b, int &mo, int &no) {
+        const int swz = xcd_remap(b, ntiles);
+        int tm, tn;
+        if (g.col_group) {
+            const int per = g.tiles_m * g.col_group;
+            const int cg = swz / per, r = swz - cg * per;
+            const int width = min(g.col_group, g.tiles_n - cg * g.col_group);
+            tm = r / width;
+            tn = cg * g.col_group + (r - tm * width);
+        } else {
+            tm = swz / g.tiles_n;
+            tn = swz - tm * g.tiles_n;
+        }
+        mo = tm * 256;
+        no = tn * 256;
+    };
+    // this wave's eight pieces of a stage: pieces wave + 8 q, q < 4 of A (rows 8 piece ..), q >= 4 of W
+    const bf16_t *gsrc[8];
+    auto set_sources = [&](int mo, int no) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // recomputed per tile: hoisted out of the tile loop, the lane terms live in scratch
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int piece = wave + 8 * (q & 3);
+            const int row = piece * 8 + (ln >> 3);
+            const int c = (ln & 7) ^ ((row >> 1) & 7);
+            const bool isw = q >= 4;
+            int grow = (isw ? no : mo) + row;
+            const int lim = isw ? g.N : g.M;
+            grow = grow < lim ? grow : lim - 1;
+            gsrc[q] = (isw ? g.W + (size_t)grow * g.ldw : g.A + (size_t)grow * g.lda) + c * 8;
+        }
+    };
+    tile_origin(vb, m0, n0);
+    set_sources(m0, n0);
+    const int a0 = lds_off(wm * 64 + frow, fq), b0 = P64_OP + lds_off(wn * 128 + frow, fq);
+    const int a1 = lds_off(wm * 64 + frow, 4 + fq), b1 = P64_OP + lds_off(wn * 128 + frow, 4 + fq);
+    const int ns = g.K / 64;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc[q] + t * 64), LDS_PTR(lds + t * P64_SLOT + (wave + 8 * q) * 1024),
+                                             16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 8; q++) gsrc[q] += 128;  // next stage to fetch: 2
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int par = 0;   // ring slot of the current tile's stage 0
+    f32x4 acc[4][8];
+    bf16x8 fa[2][4], fb[2][8];
+    const bool tracing = (g.debug_mode == 5 || g.debug_mode == 6) && threadIdx.x == 0;
+    if (tracing && blockIdx.x < TRACE_WGS)
+        g_pipe64_trace[16 * blockIdx.x + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    while (true) {
+        if (tracing && vb < TRACE_WGS) {
+            g_pipe64_trace[16 * vb] = __builtin_amdgcn_s_memrealtime();
+            g_pipe64_trace[16 * vb + 3] = g_pipe64_trace[16 * blockIdx.x + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const unsigned char *first = lds + par * P64_SLOT;
+#pragma unroll
+            for (int i = 0; i < 4; i++) fa[0][i] = *(const bf16x8 *)(first + a0 + i * 2048);
+#pragma unroll
+            for (int j = 0; j < 8; j++) fb[0][j] = *(const bf16x8 *)(first + b0 + j * 2048);
+        }
+        int s = 0;
+        for (; s < ns - 2; s++) {
+            unsigned char *cur = lds + ((par + s) & 1) * P64_SLOT, *nxt = lds + ((par + s + 1) & 1) * P64_SLOT;
+            pipe64_substep<false, false, true, 0>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, gsrc, wave);
+            pipe64_substep<true, true, true, 0>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0, cur, gsrc, wave);
+#pragma unroll
+            for (int q = 0; q < 8; q++) gsrc[q] += 64;
+            if (tracing && s < 4 && vb < TRACE_WGS) g_pipe64_trace[16 * vb + 9 + s] = __builtin_amdgcn_s_memrealtime();
+        }
+        // Stages ns - 2 and ns - 1 fetch stages 0 and 1 of this workgroup's next tile.  After the last tile they fetch its
+        // own first stages once more instead of branching around the fetch: with two versions of these sub-steps the
+        // compiler no longer accumulates in place and spills accumulators.
+        const int vb_next = vb + gridDim.x;
+        const bool more = vb_next < ntiles;
+        int m1, n1;
+        tile_origin(more ? vb_next : vb, m1, n1);
+        unsigned char *cur = lds + ((par + s) & 1) * P64_SLOT, *nxt = lds + ((par + s + 1) & 1) * P64_SLOT;
+        pipe64_substep<false, false, true, 0>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, gsrc, wave);
+        set_sources(m1, n1);
+        pipe64_substep<true, true, true, 0>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0, cur, gsrc, wave);
+#pragma unroll
+        for (int q = 0; q < 8; q++) gsrc[q] += 64;
+        pipe64_substep<false, false, true, 0>(acc, fa[0], fb[0], fa[1], fb[1], nxt + a1, nxt + b1, cur, gsrc, wave);
+        pipe64_substep<true, true, false, 0>(acc, fa[1], fb[1], fa[0], fb[0], nxt, nxt, nxt, gsrc, wave);
+#pragma unroll
+        for (int q = 0; q < 8; q++) gsrc[q] += 64;
+        if (tracing && vb < TRACE_WGS) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            g_pipe64_trace[16 * vb + 1] = t;
+            g_pipe64_trace[16 * vb + 4] = t;
+        }
+        {
+            // lane index through an opaque move: everything the epilogue derives from it is recomputed per tile; hoisted
+            // out of the tile loop it would stay live across the main loop, which has no register to spare
+            int el = lane;
+            asm volatile("" : "+v"(el));
+            if (g.debug_mode != 6)
+                epilogue_rows8<EPI>(g, acc, (float *)(lds + 2 * P64_SLOT + wave * P64P_STAGE), m0 + wm * 64, n0 + wn * 128, el);
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) asm volatile("" ::"v"(acc[i][j]));
+            }
+        }
+        if constexpr (EPI == EPI_MULGRAD) {
+            if (g.colsum) {   // uniform over the grid
+                // one atomic per column of the tile, a wave's 64 on neighbouring addresses
+                __syncthreads();
+                if (tid < 256 && n0 + tid < g.N) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        t += ((const float *)(lds + 2 * P64_SLOT + (r * 2 + (tid >> 7)) * P64P_STAGE))[tid & 127];
+                    unsafeAtomicAdd(g.colsum + n0 + tid, t);
+                }
+                __syncthreads();
+            }
+        }
+        if (tracing && vb < TRACE_WGS) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            for (int q = 5; q < 9; q++) g_pipe64_trace[16 * vb + q] = t;
+            g_pipe64_trace[16 * vb + 2] = t;
+        }
+        if (!more) break;   // (the wave's end waits for the fetches still in flight)
+        vb = vb_next;
+        m0 = m1;
+        n0 = n1;
+        par = (par + ns) & 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------
 // C_f32[M, N] += A^T B for A bf16 [Kd, M] and B bf16 [Kd, N], both ROW major (the reduction index is
 // the row): the weight gradient dW = dY^T X straight from the activations as they lie in memory, no
 // transposed copies.  256 x 256 tile, 64 reduction rows per stage, the pipeline of gemm_pipe64_kernel.
@@ -1214,6 +1510,24 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
         g.tiles_m = ceil_div(g.M, 256);
         g.tiles_n = ceil_div(g.N, 256);
         g.col_group = splits == 1 ? pipe64_col_group(g.tiles_m, g.tiles_n, g.K) : 0;
+        if constexpr (EPI != SGCLIP_EPI_F32_ATOMIC) {
+            static int persist = -1, cus = 0;
+            if (persist < 0) {
+                const char *e = getenv("SGCLIP_GEMM_PERSISTENT");
+                persist = e ? atoi(e) : 1;
+                int dev = 0;
+                if (hipGetDevice(&dev) != hipSuccess ||
+                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                    cus = 256;
+            }
+            if (persist && splits == 1 && g.wide_epilogue && (g.debug_mode == 0 || g.debug_mode == 5 || g.debug_mode == 6)) {
+                const long tiles = (long)g.tiles_m * g.tiles_n;
+                lds_attr_once((const void *)gemm_pipe64p_kernel<EPI>, P64P_LDS);
+                hipLaunchKernelGGL(gemm_pipe64p_kernel<EPI>, dim3((unsigned)std::min<long>(tiles, cus)), dim3(512), P64P_LDS,
+                                   stream, g);
+                return;
+            }
+        }
         auto go = [&](auto kernel) {
             lds_attr_once((const void *)kernel, 2 * P64_SLOT);
             hipLaunchKernelGGL(kernel, dim3((unsigned)g.tiles_m * g.tiles_n, gy), dim3(512), 2 * P64_SLOT, stream, g);

@@ -81,6 +81,39 @@ def test_gemm_epilogues(dev):
     assert (xo - want).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(70001 // 8 * 8 + 8, 768, 768), (66000, 1024, 192), (65536, 1024, 128), (20000, 3328, 320)])
+def test_gemm_many_tiles_per_workgroup(dev, M, N, K):
+    """More 256 x 256 tiles than CUs: the persistent kernel's tile loop (odd and even stage counts, two-stage tiles, a ragged
+    last tile row, a ragged last tile column) with every epilogue it serves."""
+    A = _rand_bf16((M, K), dev, 1.0, 11)
+    W = _rand_bf16((N, K), dev, K ** -0.5, 12)
+    bias = torch.randn(N, device=dev)
+    ref = A.float() @ W.float().t()
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16(A, W, out, _lib.EPI_BIAS_BF16, bias=bias)
+    assert (out.float() - (ref + bias)).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    ops.gemm_bf16(A, W, out, _lib.EPI_BIAS_GELU_BF16, bias=bias)
+    z = ref + bias
+    assert (out.float() - z * torch.sigmoid(1.702 * z)).abs().max().item() < 4e-2
+    del out, z
+    x0 = torch.randn(M, N, device=dev)
+    x = x0.clone()
+    ops.gemm_bf16(A, W, x, _lib.EPI_BIAS_RESID_F32, bias=bias)
+    assert (x - (x0 + ref + bias)).abs().max().item() < 2e-3
+    ops.gemm_bf16(A, W, x, _lib.EPI_F32)
+    assert (x - ref).abs().max().item() < 2e-3
+    P = 8
+    imgs = M // P
+    pos = torch.randn(P + 1, N, device=dev)
+    xo = torch.full((imgs * (P + 1), N), 7.0, device=dev)
+    ops.gemm_bf16(A, W, xo, _lib.EPI_PATCH_F32, aux=pos, aux_rows=P)
+    want = torch.full_like(xo, 7.0)
+    rows = torch.arange(M, device=dev)
+    want[(rows // P) * (P + 1) + 1 + rows % P] = ref + pos[1 + rows % P]
+    torch.cuda.synchronize()
+    assert (xo - want).abs().max().item() < 2e-3
+
+
 @pytest.mark.parametrize("d", [128, 512, 768, 1024])
 def test_layernorm(dev, d):
     x = torch.randn(777, d, device=dev) * 3 + 1

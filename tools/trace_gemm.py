@@ -36,6 +36,11 @@ sh = ((hw & np.uint64(0xFFFFFFFF)) >> np.uint64(12)) & np.uint64(0x1)
 slot = (xcc.astype(np.int64) * 8 + se.astype(np.int64)) * 32 + sh.astype(np.int64) * 16 + cu.astype(np.int64)
 print(f"tiles traced {n} of {tiles}; span {t2.max():.1f} us; distinct CU slots {len(np.unique(slot))}")
 ml, ep = t1 - t0, t2 - t1
+if buf[:, 9].any():
+    st = (buf[:, 9:13].astype(np.int64) - base) * 0.01
+    print("first stages of a tile, mean us: %s; remaining %d stages %.2f each" % (
+        " ".join("%.2f" % v for v in np.diff(np.concatenate([t0[:, None], st], 1), axis=1).mean(0)), K // 64 - 4,
+        (t1 - st[:, 3]).mean() / (K // 64 - 4)))
 inner = (buf[:, 4:9].astype(np.int64) - base) * 0.01
 print("epilogue of wave 0, mean us: barrier %.2f, passes %s, store acknowledgement %.2f" % (
     (inner[:, 0] - t1).mean(), " ".join("%.2f" % v for v in np.diff(inner, axis=1).mean(0)), (t2 - inner[:, 4]).mean()))
