@@ -1032,6 +1032,77 @@ __device__ __forceinline__ void epilogue_rows8(const GemmArgs &g, const f32x4 (&
     }
 }
 
+// DMA sources of the persistent kernel (see there)
+struct P64Src {
+    const unsigned char *abase, *wbase;   // uniform
+    unsigned voff_a, voff_b, max_a, max_b, chunk;
+    unsigned stride_a, stride_b;          // uniform: 64 rows in bytes
+};
+
+// 16 bytes per lane from base + min(voff + step, limit) to LDS at lds_addr + 16 * lane.  The offset arithmetic sits inside
+// the assembly so that it is redone at every fetch in one transient register: left to the compiler the eight offsets of a
+// stage are hoisted out of the stage loop into eight registers, which then spill around the tile switch.
+__device__ __forceinline__ void p64_dma16(const unsigned char *base, unsigned voff, unsigned step, unsigned limit,
+                                          unsigned lds_addr) {
+    unsigned off;
+    asm volatile("s_mov_b32 m0, %5\n\tv_add_u32 %0, %2, %1\n\tv_min_u32 %0, %0, %3\n\tglobal_load_lds_dwordx4 %0, %4"
+                 : "=&v"(off)
+                 : "v"(voff), "s"(step), "v"(limit), "s"(base), "s"(lds_addr));
+}
+
+__device__ __forceinline__ void pipe64p_fetch(const P64Src &t, unsigned char *wr_slot, int wave) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const bool isw = q >= 4;
+        p64_dma16(isw ? t.wbase : t.abase, isw ? t.voff_b : t.voff_a, (unsigned)(q & 3) * (isw ? t.stride_b : t.stride_a),
+                  isw ? t.max_b : t.max_a, (unsigned)(uintptr_t)LDS_PTR(wr_slot + (wave + 8 * q) * 1024));
+    }
+}
+
+// pipe64_substep with the sources above.  STORES > 0 with `newest_are_stores` set (uniform): the wave's STORES most recent
+// vector memory instructions are result stores of the previous tile, issued after every fetch this barrier is about; the
+// counter retires in order, so leaving that many outstanding still covers the fetches, and the stage does not wait for
+// the stores' acknowledgement.
+template <bool SYNC, bool DMA, bool READ, int DBG, int STORES = 0>
+__device__ __forceinline__ void pipe64p_substep(f32x4 (&acc)[4][8], const bf16x8 (&ca)[4], const bf16x8 (&cb)[8],
+                                                bf16x8 (&na)[4], bf16x8 (&nb)[8], const unsigned char *rd_a,
+                                                const unsigned char *rd_b, unsigned char *wr_slot, const P64Src &src, int wave,
+                                                bool newest_are_stores = false) {
+    if (SYNC) {
+        if (STORES > 0 && newest_are_stores)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STORES) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (DMA) pipe64p_fetch(src, wr_slot, wave);
+    if (READ) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) na[i] = *(const bf16x8 *)(rd_a + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 8; j++) nb[j] = *(const bf16x8 *)(rd_b + j * 2048);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+    if (READ) {
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DS_RD, 1, 0);
+        }
+    }
+}
+
+// vector memory stores one wave issues per full tile in epilogue_rows8, all after its last fetch
+template <int EPI>
+constexpr int epilogue_rows8_stores() {
+    return epi_bf16_out<EPI>() ? (EPI == EPI_GELU_BOTH ? 32 : 16) : 32;
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_pipe64p_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -1059,22 +1130,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64p_kernel(GemmArgs g) {
         mo = tm * 256;
         no = tn * 256;
     };
-    // this wave's eight pieces of a stage: pieces wave + 8 q, q < 4 of A (rows 8 piece ..), q >= 4 of W
-    const bf16_t *gsrc[8];
+    // This wave's eight pieces of a stage: pieces wave + 8 q, q < 4 of A (rows 8 piece ..), q >= 4 of W.  The source of a
+    // piece is a uniform pointer (the tile's first row at the stage's depth, in SGPRs, advanced by scalar adds) plus a
+    // 32-bit lane offset: piece 0's offset + 64 rows per further piece, limited to the operand's last row.  Four VGPRs
+    // for all sixteen sources; per-lane 64-bit pointers (sixteen) do not fit beside the accumulators and the two
+    // fragment sets, and a reload inside the loop waits for the DMA issued before it.
+    P64Src src;
+    {
+        const int row = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);   // the same for every piece: 64 rows further leaves (row >> 1) & 7
+        src.voff_a = (unsigned)(row * g.lda + c * 8) * 2u;
+        src.voff_b = (unsigned)(row * g.ldw + c * 8) * 2u;
+        src.chunk = (unsigned)c * 16u;
+    }
+    src.stride_a = 128u * (unsigned)g.lda;
+    src.stride_b = 128u * (unsigned)g.ldw;
     auto set_sources = [&](int mo, int no) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));   // recomputed per tile: hoisted out of the tile loop, the lane terms live in scratch
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int piece = wave + 8 * (q & 3);
-            const int row = piece * 8 + (ln >> 3);
-            const int c = (ln & 7) ^ ((row >> 1) & 7);
-            const bool isw = q >= 4;
-            int grow = (isw ? no : mo) + row;
-            const int lim = isw ? g.N : g.M;
-            grow = grow < lim ? grow : lim - 1;
-            gsrc[q] = (isw ? g.W + (size_t)grow * g.ldw : g.A + (size_t)grow * g.lda) + c * 8;
-        }
+        src.abase = (const unsigned char *)(g.A + (size_t)mo * g.lda);
+        src.wbase = (const unsigned char *)(g.W + (size_t)no * g.ldw);
+        src.max_a = (unsigned)(min(g.M - 1 - mo, 255) * g.lda) * 2u + src.chunk;
+        src.max_b = (unsigned)(min(g.N - 1 - no, 255) * g.ldw) * 2u + src.chunk;
     };
     tile_origin(vb, m0, n0);
     set_sources(m0, n0);
@@ -1082,18 +1157,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64p_kernel(GemmArgs g) {
     const int a1 = lds_off(wm * 64 + frow, 4 + fq), b1 = P64_OP + lds_off(wn * 128 + frow, 4 + fq);
     const int ns = g.K / 64;
 #pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc[q] + t * 64), LDS_PTR(lds + t * P64_SLOT + (wave + 8 * q) * 1024),
-                                             16, 0, 0);
-#pragma unroll
-    for (int q = 0; q < 8; q++) gsrc[q] += 128;  // next stage to fetch: 2
+    for (int t = 0; t < 2; t++) {
+        pipe64p_fetch(src, lds + t * P64_SLOT, wave);
+        src.abase += 128;   // next stage to fetch
+        src.wbase += 128;
+    }
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
     int par = 0;   // ring slot of the current tile's stage 0
+    bool after_full_tile = false;   // the previous tile of this workgroup issued every one of its result stores
     f32x4 acc[4][8];
     bf16x8 fa[2][4], fb[2][8];
     const bool tracing = (g.debug_mode == 5 || g.debug_mode == 6) && threadIdx.x == 0;
@@ -1119,10 +1193,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64p_kernel(GemmArgs g) {
         int s = 0;
         for (; s < ns - 2; s++) {
             unsigned char *cur = lds + ((par + s) & 1) * P64_SLOT, *nxt = lds + ((par + s + 1) & 1) * P64_SLOT;
-            pipe64_substep<false, false, true, 0>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, gsrc, wave);
-            pipe64_substep<true, true, true, 0>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0, cur, gsrc, wave);
-#pragma unroll
-            for (int q = 0; q < 8; q++) gsrc[q] += 64;
+            pipe64p_substep<false, false, true, 0>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, src, wave);
+            pipe64p_substep<true, true, true, 0, epilogue_rows8_stores<EPI>()>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0,
+                                                                              cur, src, wave, s == 0 && after_full_tile);
+            src.abase += 128;
+            src.wbase += 128;
             if (tracing && s < 4 && vb < TRACE_WGS) g_pipe64_trace[16 * vb + 9 + s] = __builtin_amdgcn_s_memrealtime();
         }
         // Stages ns - 2 and ns - 1 fetch stages 0 and 1 of this workgroup's next tile.  After the last tile they fetch its
@@ -1133,15 +1208,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64p_kernel(GemmArgs g) {
         int m1, n1;
         tile_origin(more ? vb_next : vb, m1, n1);
         unsigned char *cur = lds + ((par + s) & 1) * P64_SLOT, *nxt = lds + ((par + s + 1) & 1) * P64_SLOT;
-        pipe64_substep<false, false, true, 0>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, gsrc, wave);
+        pipe64p_substep<false, false, true, 0>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, src, wave);
         set_sources(m1, n1);
-        pipe64_substep<true, true, true, 0>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0, cur, gsrc, wave);
-#pragma unroll
-        for (int q = 0; q < 8; q++) gsrc[q] += 64;
-        pipe64_substep<false, false, true, 0>(acc, fa[0], fb[0], fa[1], fb[1], nxt + a1, nxt + b1, cur, gsrc, wave);
-        pipe64_substep<true, true, false, 0>(acc, fa[1], fb[1], fa[0], fb[0], nxt, nxt, nxt, gsrc, wave);
-#pragma unroll
-        for (int q = 0; q < 8; q++) gsrc[q] += 64;
+        pipe64p_substep<true, true, true, 0>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0, cur, src, wave);
+        src.abase += 128;
+        src.wbase += 128;
+        pipe64p_substep<false, false, true, 0>(acc, fa[0], fb[0], fa[1], fb[1], nxt + a1, nxt + b1, cur, src, wave);
+        pipe64p_substep<true, true, false, 0>(acc, fa[1], fb[1], fa[0], fb[0], nxt, nxt, nxt, src, wave);
+        src.abase += 128;
+        src.wbase += 128;
         if (tracing && vb < TRACE_WGS) {
             const unsigned long long t = __builtin_amdgcn_s_memrealtime();
             g_pipe64_trace[16 * vb + 1] = t;
@@ -1181,6 +1256,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64p_kernel(GemmArgs g) {
             g_pipe64_trace[16 * vb + 2] = t;
         }
         if (!more) break;   // (the wave's end waits for the fetches still in flight)
+        after_full_tile = m0 + 256 <= g.M && n0 + 256 <= g.N && (g.debug_mode == 0 || g.debug_mode == 5) && !(EPI == EPI_MULGRAD && g.colsum);
         vb = vb_next;
         m0 = m1;
         n0 = n1;
