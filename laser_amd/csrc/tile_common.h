@@ -21,6 +21,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 constexpr float NEG_BIG = -1.0e30f;
+// The running maximum of the online softmax is only a reference point: any value works as long as the exponentials stay
+// in range.  It moves only when a block's maximum exceeds it by more than this many binary orders of magnitude, so the
+// weights reach at most 2^8 (exact in bf16, harmless in the fp32 sums) and the output accumulators are rescaled once or
+// twice per row instead of in almost every key block.
+constexpr float SOFTMAX_SLACK = 8.0f;
 
 // One key block of the online softmax, in the base-2 domain (scores * 0.125 * log2 e).
 // st: S^T accumulators of this lane's query (register g = key n0 + (g&3) + 8*(g>>2) + 4*h); on
@@ -49,7 +54,7 @@ __device__ __forceinline__ float online_softmax_step(f32x16 &st, float &m_run, f
             mx = fmaxf(mx, t);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        m_new = fmaxf(m_run, mx);
+        m_new = mx > m_run + SOFTMAX_SLACK ? mx : m_run;
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             float p = __builtin_amdgcn_exp2f(st[g] - m_new);
@@ -63,7 +68,7 @@ __device__ __forceinline__ float online_softmax_step(f32x16 &st, float &m_run, f
 #pragma unroll
         for (int g = 0; g < 16; g++) mx = fmaxf(mx, st[g]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        m_new = fmaxf(m_run, mx * C);
+        m_new = mx * C > m_run + SOFTMAX_SLACK ? mx * C : m_run;
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[g], C, -m_new));
