@@ -2,12 +2,14 @@
 the same op (torch on the same device) or, for the byte-exact crop kernel,
 against the CPU oracle and the golden vectors."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from laser_amd import _lib, ops  # noqa: E402
 
@@ -394,3 +396,36 @@ def test_crop_errors(dev):
         ops.crop_preprocess(frames_t, None, _entries([(0, -1, -1, 100, 100, 10, 10, 120, 20, _lib.CROP_PLAIN)]), 64)
     with pytest.raises(_lib.SgclipError):
         ops.crop_preprocess(frames_t, None, _entries([(0, -1, -1, 100, 100, 10, 10, 50, 20, _lib.CROP_OBJECT)]), 64)
+
+
+def test_crop_sweep_at_720p_vs_oracle(dev):
+    """Boxes drawn log-uniformly in size on 1280 x 720 frames (the benchmark's distribution) plus thin, tiny and
+    frame-sized ones, all crop modes, S = 224: every variant of the matrix-core crop kernel and the vector kernel it
+    leaves the rest to, bit for bit against the oracle (tools/fuzz_crop.py runs the same sweep at any length)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_crop", os.path.join(ROOT, "tools", "fuzz_crop.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from oracle import crop_ref, resample_ref
+    rng = np.random.default_rng(77)
+    H, W = 720, 1280
+    frames = (rng.integers(0, 256, size=(2, H, W, 3)) // 2 + np.linspace(0, 127, W)[None, None, :, None]).astype(np.uint8)
+    masks = rng.random((3, H, W)) < 0.4
+    frames_t = torch.from_numpy(ops.pad_bytes(frames)).to(dev)
+    masks_t = torch.from_numpy(ops.pad_bytes(masks.astype(np.uint8))).to(dev)
+    boxes = fz.draw_boxes(rng, 160, W, H)
+    rows = []
+    for i, (x1, y1, x2, y2) in enumerate(boxes):
+        mode = (_lib.CROP_OBJECT, _lib.CROP_PAIR, _lib.CROP_PAIR, _lib.CROP_PLAIN)[i % 4]
+        rows.append(((i % 2) * H * W * 3, (i % 3) * H * W, ((i + 1) % 3) * H * W, W, H, x1, y1, x2, y2, mode))
+    out = ops.crop_preprocess(frames_t, masks_t, _entries(rows), 224).cpu().numpy()
+    blended = {}
+    for i, (foff, aoff, boff, _, _, x1, y1, x2, y2, mode) in enumerate(rows):
+        key = (foff, aoff, boff, mode)
+        if key not in blended:
+            fr = frames[foff // (H * W * 3)]
+            ma, mb = masks[aoff // (H * W)][..., None], masks[boff // (H * W)][..., None]
+            blended[key] = (crop_ref.extract_single_object(fr, ma, 0.8) if mode == _lib.CROP_OBJECT else
+                            crop_ref.extract_object_subject(fr, ma, mb, 0.5, 0.8) if mode == _lib.CROP_PAIR else fr)
+        want = resample_ref.preprocess(blended[key][y1:y2, x1:x2], 224)
+        assert np.array_equal(out[i], want), f"crop {i} box {boxes[i]} mode {mode}: {(out[i] != want).sum()} values differ"
