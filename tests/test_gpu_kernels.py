@@ -429,3 +429,20 @@ def test_crop_sweep_at_720p_vs_oracle(dev):
                             crop_ref.extract_object_subject(fr, ma, mb, 0.5, 0.8) if mode == _lib.CROP_PAIR else fr)
         want = resample_ref.preprocess(blended[key][y1:y2, x1:x2], 224)
         assert np.array_equal(out[i], want), f"crop {i} box {boxes[i]} mode {mode}: {(out[i] != want).sum()} values differ"
+
+
+def test_gemm_many_tiles_with_padded_leading_dimensions(dev):
+    """The persistent kernel's lane-offset addressing with operands whose rows are further apart than K (views into
+    wider buffers, as the towers' strided operands are), ragged in both tile directions."""
+    M, N, K, pad = 66000 + 40, 768 + 128, 448, 64
+    A = _rand_bf16((M, K + pad), dev, 1.0, 21)[:, :K]
+    W = _rand_bf16((N, K + 2 * pad), dev, K ** -0.5, 22)[:, pad:pad + K]
+    bias = torch.randn(N, device=dev)
+    ref = A.float() @ W.float().t() + bias
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    ops.gemm_bf16(A, W, out, _lib.EPI_BIAS_BF16, bias=bias)
+    assert (out.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    x0 = torch.randn(M, N, device=dev)
+    x = x0.clone()
+    ops.gemm_bf16(A, W, x, _lib.EPI_BIAS_RESID_F32, bias=bias)
+    assert (x - (x0 + ref)).abs().max().item() < 2e-3
