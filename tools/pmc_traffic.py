@@ -25,8 +25,8 @@ def main():
     f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 1 "
                    "--no-cpu-baseline`; KB per launch averaged per kernel; corrected bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-                   "(gfx950 FETCH_SIZE counts half of wide streaming reads); that command makes three passes over the step "
-                   "(warm-up, timed step, one-stream kernel pass)", "passes": 3, "kernels": {}}
+                   "(gfx950 FETCH_SIZE counts half of wide streaming reads); that command makes eight passes over the step "
+                   "(warm-up, timed step, five single-clip latency steps, one-stream kernel pass)", "passes": 8, "kernels": {}}
     for k in f:
         if not k.startswith("sgclip::"):
             continue
