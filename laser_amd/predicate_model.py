@@ -15,7 +15,6 @@ from __future__ import annotations
 import os
 
 import functools
-import warnings
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -132,7 +131,9 @@ class PredicateModel(nn.Module):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError(f"laser_amd.PredicateModel runs on a GPU device, got {device!r}")
-        self.cfg = config or config_by_name(model_name)
+        # any CLIP geometry the reference's AutoModel.from_pretrained(model_name) would build (:15-23): a hub name whose
+        # geometry is known offline, a local HF snapshot directory / config.json, an HF config dict, or a ClipConfig
+        self.cfg = config_by_name(config if config is not None else model_name)
         self.num_top_pairs = num_top_pairs
         self.use_sparse = False
         if tokenizer is None:
@@ -151,14 +152,17 @@ class PredicateModel(nn.Module):
 
     # -- weights ---------------------------------------------------------------
     def _default_tokenizer(self, model_name):
+        """The reference's AutoTokenizer.from_pretrained(model_name) (:15), from local files only.  Without the
+        vocabulary files it raises, as the reference does: a stand-in tokenizer under real weights would score
+        confidently against the wrong token ids.  Tests and benchmarks pass `tokenizer=` explicitly."""
         try:
             from transformers import AutoTokenizer
             return AutoTokenizer.from_pretrained(model_name, local_files_only=True)
-        except Exception as e:  # no vocabulary files on this machine
-            from .tokenizer import HashTokenizer
-            warnings.warn(f"CLIP tokenizer files for {model_name!r} are not available ({type(e).__name__}); "
-                          f"falling back to the deterministic HashTokenizer")
-            return HashTokenizer(self.cfg.vocab, self.cfg.bos_token_id, self.cfg.eos_token_id)
+        except Exception as e:
+            raise OSError(f"no CLIP tokenizer files for {model_name!r} on this machine (looked in the local HuggingFace "
+                          f"cache / path only, HF_HOME={os.environ.get('HF_HOME', '~/.cache/huggingface')!r}; "
+                          f"{type(e).__name__}: {e}).  Pass tokenizer=<a CLIPTokenizer> (or, for synthetic weights, "
+                          f"laser_amd.tokenizer.HashTokenizer) to PredicateModel.") from e
 
     def invalidate_packed_weights(self):
         self._towers = None

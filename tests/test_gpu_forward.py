@@ -230,6 +230,50 @@ def test_vit_l14_336_tower_in_bulk_matches_small_batches_and_oracle():
     print(f"L/14-336 bulk tower: rel err vs oracle {rel:.2e}, vs small batches {rel_small:.2e}")
 
 
+@pytest.mark.parametrize("cfg_name,n", [("openai/clip-vit-base-patch16", 260), ("openai/clip-vit-large-patch14", 140)])
+def test_other_clip_geometries_towers_match_oracle(cfg_name, n):
+    """The remaining OpenAI CLIP geometries the reference's `--clip-model-name` reaches (scripts/eval_sgclip.py:34-95 ->
+    laser/models/llava_clip_model_v3.py:15-23): ViT-B/16 (T = 197) and ViT-L/14 at 224 px (T = 257), sequence lengths
+    between the fused q/k/v + attention kernel (T <= 128) and ViT-L/14-336's 577.  Enough crops for the bulk kernels:
+    every crop against the same tower in small batches, sampled crops and the text tower against the fp32 oracle."""
+    from laser_amd import _lib, ops
+    from laser_amd.weights import random_state_dict
+    from laser_amd.predicate_model import CROP_DTYPE
+    from oracle import clip_ref, resample_ref
+    cfg = config_by_name(cfg_name)
+    sd = random_state_dict(cfg, 31)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(16)
+    H, W = 300, 400
+    frame = (rng.integers(0, 256, size=(H, W, 3)) // 2 + np.linspace(0, 127, W)[None, :, None]).astype(np.uint8)
+    x1 = rng.integers(0, W - 60, n); y1 = rng.integers(0, H - 60, n)
+    x2 = np.minimum(W, x1 + rng.integers(40, 300, n)); y2 = np.minimum(H, y1 + rng.integers(40, 250, n))
+    rows = [(0, -1, -1, W, H, int(a), int(b), int(c), int(d), _lib.CROP_PLAIN, 0) for a, b, c, d in zip(x1, y1, x2, y2)]
+    frames_t = torch.from_numpy(ops.pad_bytes(frame)).to(dev)
+    patches = ops.crop_preprocess(frames_t, None, np.array(rows, dtype=CROP_DTYPE), cfg.image, layout=_lib.LAYOUT_PATCHES,
+                                  patch=cfg.patch, out_dtype=_lib.DTYPE_BF16)
+    tower = ops.Tower(cfg, "vision", sd, dev)
+    got = tower.encode_images(patches, n)
+    P = cfg.n_patches
+    small = torch.cat([tower.encode_images(patches[i * P:(i + 8) * P], min(8, n - i)) for i in range(0, n, 8)])
+    torch.cuda.synchronize()
+    rel_small = ((got - small).norm(dim=-1) / small.norm(dim=-1)).max().item()
+    assert rel_small < 5e-3, rel_small
+    pick = [0, 1, n - 1]
+    px = torch.from_numpy(np.stack([resample_ref.preprocess(frame[y1[i]:y2[i], x1[i]:x2[i]], cfg.image) for i in pick]))
+    torch.set_num_threads(16)
+    want = clip_ref.image_features(sd, cfg, px)
+    rel = ((got[pick].cpu() - want).norm(dim=-1) / want.norm(dim=-1)).max().item()
+    assert rel < 1e-2, rel
+    tok = HashTokenizer(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    t = tok(["a person riding a horse", "dog", "the quick brown fox jumps over the lazy dog " * 12])
+    tgot = ops.Tower(cfg, "text", sd, dev).encode_text(t["input_ids"], t["attention_mask"]).cpu()
+    twant = clip_ref.text_features(sd, cfg, t["input_ids"], t["attention_mask"])
+    trel = ((tgot - twant).norm(dim=-1) / twant.norm(dim=-1)).max().item()
+    assert trel < 1e-2, trel
+    print(f"{cfg_name}: image feature rel err vs oracle {rel:.2e}, vs small batches {rel_small:.2e}, text {trel:.2e}")
+
+
 def test_concurrent_towers_give_the_single_stream_result():
     """forward() queues the unary tower and the halves of a large pair set on side streams; the result must be the
     bits of the single-stream call, twice in a row (the second call reuses every workspace and stream)."""

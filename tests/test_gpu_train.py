@@ -243,11 +243,12 @@ def _compare_gradients(model, towers, per_tensor_tol, total_tol):
     return total
 
 
-@pytest.mark.parametrize("cfg_name,objects,frames", [("vit-b-32", 5, 2), ("vit-l-14-336", 2, 1)])
+@pytest.mark.parametrize("cfg_name,objects,frames", [("vit-b-32", 5, 2), ("vit-l-14-336", 2, 1), ("vit-b-16", 3, 1), ("vit-l-14", 2, 1)])
 def test_train_gradients_at_real_width_match_the_oracle(cfg_name, objects, frames):
     """The train step of scripts/train_sgclip.py:682-694, 877-890 (forward under autograd with the spec's binary
-    predicates selecting the pairs, loss.backward()) at the real CLIP geometries: ViT-B/32, and ViT-L/14 at 336 px
-    whose 577-token sequences run the blocked attention adjoint.  Selected pair keys bit-exact, probabilities within
+    predicates selecting the pairs, loss.backward()) at the real CLIP geometries: ViT-B/32, ViT-L/14 at 336 px
+    whose 577-token sequences run the blocked attention adjoint, and the two geometries in between (ViT-B/16 with 197
+    tokens, ViT-L/14 at 224 px with 257).  Selected pair keys bit-exact, probabilities within
     2e-2, every parameter gradient against fp32 autograd of the CPU oracle."""
     cfg = config_by_name(cfg_name)
     sd = predicate_model_state_dict(cfg, 27, float(np.log(20.0)))

@@ -135,3 +135,43 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("a GPU is visible")
     with pytest.raises(RuntimeError, match="no CPU path|no GPU"):
         PredicateModel(None, None, "cuda", "tiny", tokenizer=HashTokenizer(1024))
+
+
+def test_missing_tokenizer_files_fail_loudly():
+    """Without vocabulary files the reference's AutoTokenizer.from_pretrained raises
+    (laser/models/llava_clip_model_v3.py:15); so does the default tokenizer here, naming where it looked."""
+    with pytest.raises(OSError, match="(?s)no CLIP tokenizer files for .no-such-org/no-such-clip..*tokenizer="):
+        PredicateModel._default_tokenizer(None, "no-such-org/no-such-clip")
+
+
+def test_any_clip_geometry_from_a_name_a_snapshot_or_a_config_dict(tmp_path):
+    """The reference builds whatever AutoModel.from_pretrained(model_name) names
+    (laser/models/llava_clip_model_v3.py:15-23); here: the hub names with a known geometry, a local HF
+    snapshot directory, a config.json path or its dict."""
+    import json
+    from laser_amd.config import VIT_B16, VIT_L14, config_by_name, from_hf_config
+    assert config_by_name("openai/clip-vit-base-patch16") is VIT_B16 and VIT_B16.v_tokens == 197
+    assert config_by_name("openai/clip-vit-large-patch14") is VIT_L14 and VIT_L14.v_tokens == 257
+    assert config_by_name("openai/clip-vit-large-patch14-336") is VIT_L14_336
+    hf = {"model_type": "clip", "projection_dim": 768, "logit_scale_init_value": 2.6592,
+          "vision_config": {"hidden_size": 1024, "intermediate_size": 4096, "num_hidden_layers": 24, "num_attention_heads": 16,
+                            "patch_size": 14, "image_size": 224, "hidden_act": "quick_gelu", "layer_norm_eps": 1e-5},
+          "text_config": {"hidden_size": 768, "intermediate_size": 3072, "num_hidden_layers": 12, "num_attention_heads": 12,
+                          "vocab_size": 49408, "max_position_embeddings": 77, "eos_token_id": 49407, "bos_token_id": 49406}}
+    assert from_hf_config(hf) == VIT_L14
+    assert from_hf_config({}) == VIT_B32                      # HF CLIPConfig() defaults are the B/32 geometry
+    assert from_hf_config({"text_config": {"eos_token_id": 2}}).eos_token_id == 2     # the argmax pooling branch's marker
+    (tmp_path / "config.json").write_text(json.dumps(hf))
+    assert config_by_name(str(tmp_path)) == VIT_L14
+    assert config_by_name(tmp_path / "config.json") == VIT_L14
+    assert config_by_name(hf) == VIT_L14
+    with pytest.raises(KeyError, match="local HF snapshot"):
+        config_by_name("laion/CLIP-ViT-H-14-laion2B-s32B-b79K")
+    bad = json.loads(json.dumps(hf))
+    bad["vision_config"].update(hidden_size=1280, num_attention_heads=16)      # ViT-H: head width 80
+    with pytest.raises(ValueError, match="head width"):
+        from_hf_config(bad)
+    bad = json.loads(json.dumps(hf))
+    bad["text_config"]["hidden_act"] = "gelu"
+    with pytest.raises(ValueError, match="quick_gelu"):
+        from_hf_config(bad)
