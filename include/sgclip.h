@@ -245,6 +245,28 @@ int sgclip_gemm_mulgelugrad_bf16(const void *A_dev, int lda, const void *W_dev, 
  * hi + lo halves on the MFMA (three products), error ~2^-16 relative; in % 16 == 0. */
 int sgclip_linear_f32(const float *x_dev, const float *w_dev, int rows, int out_features, int in_features,
                       float *y_dev, void *stream);
+/* The linear layers and the attention of an encoder layer in the reference's own fp32 arithmetic
+ * (nn.Linear / softmax attention as transformers models/clip/modeling_clip.py:269-277, 298-350 runs them under
+ * laser/models/llava_clip_model_v3.py:77-83): exact fp32 products with fp32 accumulation on the fp32 matrix
+ * cores.  Used to re-score the few crops on which the training-mode pair selection hangs
+ * (llava_clip_model_v3.py:303-314, 347-386) when the bf16 towers leave the ranking undecided.
+ * y = epi(x W^T + bias), x f32 [rows, in] (row stride ldx), W f32 [out, in] (ldw), bias f32 [out] or NULL,
+ * y f32 (row stride ldy); in % 8 == 0, operand rows 16-byte aligned.  mode:                            */
+#define SGCLIP_F32_PLAIN 0 /* y[m] = x W^T + bias                                                      */
+#define SGCLIP_F32_GELU 1  /* y[m] = quick_gelu(x W^T + bias)                                          */
+#define SGCLIP_F32_RESID 2 /* y[m] = aux[m] + x W^T + bias (aux f32, row stride ldy; may be y itself)  */
+#define SGCLIP_F32_PATCH 3 /* y[(m / aux_rows) * out_tokens + 1 + m % aux_rows] = x W^T + aux[1 + m % aux_rows]:
+                            * patch embedding + position rows (aux = position table, row stride ldy)   */
+int sgclip_linear_exact_f32(const float *x_dev, int64_t ldx, const float *w_dev, int64_t ldw, const float *bias_dev,
+                            int rows, int out_features, int in_features, int mode, const float *aux_dev,
+                            int aux_rows, int out_tokens, float *y_dev, int64_t ldy, void *stream);
+/* qkv f32 [n_seq*T, 3d] -> out f32 [n_seq*T, d]: softmax(q k^T / 8 + mask) v per head of 64, all in fp32;
+ * causal and key_mask_dev (int32 [n_seq, T], NULL = all ones) as in sgclip_attention.                   */
+int sgclip_attention_f32(const float *qkv_dev, float *out_dev, int n_seq, int T, int heads, int causal,
+                         const int32_t *key_mask_dev, void *stream);
+/* x[k][n] <- scale * x[k][n], then (do_softmax) softmax over k for every column n, in place: the tail of clip_sim
+ * and the .softmax(dim=0) behind it (llava_clip_model_v3.py:41-47, :275) for logits already formed in fp32. */
+int sgclip_scale_softmax_columns(float *x_dev, int K, int N, float scale, int do_softmax, void *stream);
 /* y[r] = LayerNorm(x[row(r)]) * w + b; row(r) = row_idx_dev ? row_idx_dev[r] : r;
  * x f32 with row stride x_stride elements; y bf16 or f32, contiguous rows.   */
 int sgclip_layernorm(const float *x_dev, int64_t x_stride, const int32_t *row_idx_dev, int rows, int d,

@@ -21,6 +21,7 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 SIM_LOGIT, SIM_SOFTMAX, SIM_SIGMOID = 0, 1, 2
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_RESID_F32, EPI_PATCH_F32, EPI_F32, EPI_F32_ATOMIC = 0, 1, 2, 3, 4, 5
 EPI_BIAS_GELU_BOTH_BF16, EPI_BIAS_MULGELUGRAD_BF16 = 6, 7
+F32_PLAIN, F32_GELU, F32_RESID, F32_PATCH = 0, 1, 2, 3
 CROP_LUT_BYTES = 768 + 768 * 4
 
 (T_PATCH_W, T_CLS, T_POS, T_PRE_LN_W, T_PRE_LN_B, T_LN1_W, T_LN1_B, T_QKV_W, T_QKV_B, T_O_W, T_O_B, T_LN2_W,
@@ -76,6 +77,10 @@ SIGNATURES = {
     "sgclip_gemm_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "sgclip_linear_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "sgclip_linear_exact_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "sgclip_attention_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "sgclip_scale_softmax_columns": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "sgclip_layernorm": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "sgclip_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -148,6 +148,18 @@ class PredicateModel(nn.Module):
         self._train_towers = None    # training-form towers over the fp32 parameters (built on first use)
         self._text_cache: Dict = {}
         self.cache_text_features = True
+        # Training-mode pair selection (:347-386) is a discrete function of a floating-point ranking.  With the guard on,
+        # objects whose mean category probability lies within the bf16 towers' error of the boundary between the
+        # `topk_cate`-th and the next candidate of a name the predicates use are scored again in fp32
+        # (laser_amd/rescore.py) before ranking.  rank_guard_cos_err: bound on the error of a cosine similarity through
+        # the bf16 towers; rank_exact_cos_err: the same for the fp32 path (two fp32 evaluations of a tower that add in
+        # different orders differ by this much).  What the guard did in the last forward() is in `ranking_report`;
+        # boundaries that stay closer than the fp32 bound are listed there with decided=False and warned about.
+        self.rank_guard = True
+        self.rank_guard_cos_err = 2.5e-3
+        self.rank_exact_cos_err = 4e-6
+        self.ranking_report: List[dict] = []
+        self._exact_towers: Dict = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed_weights())
 
     # -- weights ---------------------------------------------------------------
@@ -359,6 +371,93 @@ class PredicateModel(nn.Module):
             return training.similarity(text, img, self._trainers()[prefix][2], mode)
         return ops.similarity(text, img, self._packed()[prefix][2], mode)
 
+    # -- ranking guard -----------------------------------------------------------
+    def _exact(self, prefix: str):
+        """(vision, text) fp32 towers over the model's own fp32 parameters, built on first use."""
+        if prefix not in self._exact_towers:
+            from .rescore import ExactTower
+            params = dict(self._modules[prefix].named_parameters())
+            self._exact_towers[prefix] = (ExactTower(self.cfg, "vision", params), ExactTower(self.cfg, "text", params), params)
+        return self._exact_towers[prefix]
+
+    def _rank_guard(self, vid, host, c_rows, names, oids, seg_host, table, di, preds, topk, alpha, white_alpha, softmax,
+                    pool):
+        """Returns `host` (per-object mean category scores [rows of c_rows, objects], float64 on the host) with the
+        columns of every object the ranking's outcome depends on replaced by fp32 values.
+
+        The selected pairs depend on the SET of the best `topk` objects of each name the predicates mention
+        (:350-357, 368-386).  With each value known up to its error bound, the set is certain once the lowest
+        possible value inside it exceeds the highest possible value outside; while it is not, the bf16-scored
+        objects that straddle the boundary are scored again in fp32 (all their frames, the whole vocabulary, mean
+        over frames as in :303-311) and the test is repeated with their error bound reduced to the fp32 one."""
+        from . import rescore
+        used = set()
+        for pred in preds or []:
+            used.add(pred[1]); used.add(pred[2])
+        rows = [(r, nm) for r, nm in c_rows if nm in used]
+        if not rows:
+            return host
+        G_ = len(oids)
+        vis, txt, params = self._exact("clip_cate_model")
+        scale = float(params["logit_scale"].detach().exp())
+        exact = np.zeros(G_, dtype=bool)
+        seg = np.asarray(seg_host, dtype=np.int64)
+        text_exact = None
+
+        def bounds(v, is_exact):
+            cos_err = np.where(is_exact, self.rank_exact_cos_err, self.rank_guard_cos_err)
+            # a logit moves by scale * cos_err; a softmax probability by at most that fraction of itself (twice: the
+            # normaliser moves too)
+            return np.minimum(1.0, 2.0 * scale * cos_err) * np.abs(v) if softmax else scale * cos_err * np.ones_like(v)
+
+        def undecided():
+            todo, open_rows = set(), []
+            for r, nm in rows:
+                v = host[r]
+                order = np.argsort(-v, kind="stable")
+                inside, outside = order[:topk], order[topk:]
+                eps = bounds(v, exact)
+                lo_in, hi_out = (v - eps)[inside].min(), (v + eps)[outside].max()
+                if lo_in > hi_out:
+                    continue
+                strad = [g for g in inside if v[g] - eps[g] <= hi_out] + [g for g in outside if v[g] + eps[g] >= lo_in]
+                open_rows.append((nm, float(v[inside].min() - v[outside].max()), len(strad)))
+                todo.update(int(g) for g in strad if not exact[g])
+            return todo, open_rows
+
+        n_rescored = 0
+        while True:
+            todo, open_rows = undecided()
+            if not todo:
+                break
+            groups = sorted(todo)
+            cols = np.nonzero(np.isin(seg, groups))[0]
+            sub = np.ascontiguousarray(table[cols])
+            patches = ops.crop_preprocess(di.frames, di.masks, sub, self.cfg.image, layout=_lib.LAYOUT_PATCHES,
+                                          patch=self.cfg.patch, out_dtype=_lib.DTYPE_F32, alpha=alpha, white_alpha=white_alpha)
+            feats = vis.image_features(patches, len(cols))
+            if text_exact is None:
+                tokens = self.clip_tokenizer(list(names), return_tensors="pt", max_length=75, truncation=True,
+                                             padding="max_length")
+                am = tokens.get("attention_mask") if hasattr(tokens, "get") else tokens["attention_mask"]
+                text_exact = txt.text_features(tokens["input_ids"], am)
+            dense = rescore.probabilities_exact(text_exact, feats, scale, softmax)
+            local = {g: j for j, g in enumerate(groups)}
+            seg_local = torch.tensor([local[int(seg[c])] for c in cols], dtype=torch.int32, device=self.device)
+            mean = pool(ops.segment_mean(dense, seg_local, len(groups))).detach().cpu().numpy().astype(np.float64)
+            host = host.copy()
+            host[:, groups] = mean
+            exact[groups] = True
+            n_rescored += len(groups)
+        for nm, margin, n in open_rows:
+            import warnings
+            warnings.warn(f"pair selection of video {vid}: the candidates of {nm!r} at the top-{topk} boundary differ by "
+                          f"{margin:.3e}, below what fp32 arithmetic resolves; the selected pairs may differ from another "
+                          f"fp32 implementation's")
+        self.ranking_report.append({"video": vid, "objects": G_, "rescored": n_rescored,
+                                    "undecided": [(nm, margin) for nm, margin, _ in open_rows]})
+        return host
+
     # -- forward ---------------------------------------------------------------
     @_no_grad_unless_training
     def forward(self, batched_video_ids, batched_videos, batched_masks, batched_bboxes, batched_names,
@@ -384,6 +483,7 @@ class PredicateModel(nn.Module):
         batched_unary_kws = fill_empty(batched_unary_kws)
         batched_binary_kws = fill_empty(batched_binary_kws)
         dummy_terms: List[torch.Tensor] = []
+        self.ranking_report = []
 
         # Step 1: text features of the three vocabularies (:137-186)
         name_feats = [self._text_features("clip_cate_model", n) for n in batched_names]
@@ -493,8 +593,12 @@ class PredicateModel(nn.Module):
                 for r, nm in enumerate(names):
                     if nm != dummy_str:
                         uniq.setdefault(nm, []).append(r)
-                if any(len(rs) > 1 for rs in uniq.values()):
-                    cate_mean = torch.stack([cate_mean[rs].mean(dim=0) for rs in uniq.values()])
+                pooled_names = any(len(rs) > 1 for rs in uniq.values())
+
+                def pool(mean, uniq=uniq, pooled_names=pooled_names):
+                    return torch.stack([mean[rs].mean(dim=0) for rs in uniq.values()]) if pooled_names else mean
+                cate_mean = pool(cate_mean)
+                if pooled_names:
                     c_rows = list(enumerate(uniq.keys()))
                 else:
                     c_rows = [(r, nm) for r, nm in enumerate(names) if nm != dummy_str]
@@ -503,7 +607,11 @@ class PredicateModel(nn.Module):
                 unary_out[vid] = ProbDict(unary_dense, u_rows, list(enumerate(object_ids)),
                                           lambda fo, nm: (fo[0], fo[1], nm), "row_major")
                 if need_ranking:
-                    host = cate_mean.detach().cpu()
+                    host = cate_mean.detach().cpu().numpy().astype(np.float64)
+                    if self.rank_guard and len(oids) > topk_cate:
+                        host = self._rank_guard(vid, host, c_rows, names, oids, seg_host, obj_table[s:e], di,
+                                                batched_binary_predicates[vid], topk_cate, alpha, white_alpha,
+                                                not output_logit, pool)
                     # per category: (prob, oid) sorted descending, ties by descending oid (:313-314)
                     obj_per_cate_all[vid] = {nm: sorted([(float(host[r, g]), oid) for g, oid in enumerate(oids)], reverse=True)
                                              for r, nm in c_rows}
