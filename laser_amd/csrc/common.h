@@ -21,6 +21,12 @@ namespace sgclip {
 // thread-local error text behind sgclip_last_error()
 void set_error(const char *fmt, ...);
 int launch_check(const char *what);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) for `fn` on the CURRENT device, once per (kernel, device): the
+// attribute belongs to the device's own function object, so a second GPU in the process needs its own call.
+// false + error text when HIP refuses.
+bool lds_attr(const void *fn, int bytes);
+// compute units of the current device (cached per device)
+int device_cus();
 
 // Opt-in per-kernel timing (sgclip_timing_*): when enabled, a KernelTimer in a launch
 // function brackets the launch with two HIP events on the launch stream.

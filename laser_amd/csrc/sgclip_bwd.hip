@@ -590,12 +590,7 @@ static void attention_bwd_mfma_launch(const bf16_t *qkv, const bf16_t *dout, bf1
     constexpr size_t phase_a = (size_t)4 * TP * 72 * 2, phase_b = (size_t)3 * TP * LDT * 2;
     constexpr size_t lds = (size_t)3 * 64 * LDT * 2 + (phase_a > phase_b ? phase_a : phase_b);
     static_assert(lds <= 160 * 1024, "attention backward tile exceeds the LDS");
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)attention_bwd_mfma_kernel<TP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
-        attr = true;
-    }
+    if (!lds_attr((const void *)attention_bwd_mfma_kernel<TP>, (int)lds)) return;   // the error text is set; launch_check reports it
     hipLaunchKernelGGL(attention_bwd_mfma_kernel<TP>, dim3((unsigned)(n_seq * heads)), dim3(256), lds, stream, qkv, dout, dqkv,
                        T, heads, causal, km);
 }
@@ -1117,12 +1112,7 @@ extern "C" int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, v
                       "16-byte aligned", T);
             return SGCLIP_EINVAL;
         }
-        static bool attr_long = false;
-        if (!attr_long) {
-            (void)hipFuncSetAttribute((const void *)attention_bwd_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-            attr_long = true;
-        }
+        if (!lds_attr((const void *)attention_bwd_long_kernel, 160 * 1024)) return SGCLIP_ELAUNCH;
         hipLaunchKernelGGL(attention_bwd_long_kernel, dim3((unsigned)(n_seq * heads)), dim3(256), lds, (hipStream_t)stream,
                            (const bf16_t *)qkv_dev, (const bf16_t *)dout_dev, (bf16_t *)dqkv_dev, T, heads, causal, key_mask_dev);
         return launch_check("sgclip_attention_bwd");
@@ -1147,11 +1137,7 @@ extern "C" int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, v
         return launch_check("sgclip_attention_bwd");
     }
     const size_t lds = (size_t)4 * T * 64 * sizeof(bf16_t) + (size_t)T * T * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    if (!lds_attr((const void *)attention_bwd_kernel, 160 * 1024)) return SGCLIP_ELAUNCH;
     hipLaunchKernelGGL(attention_bwd_kernel, dim3((unsigned)(n_seq * heads)), dim3(256), lds, (hipStream_t)stream,
                        (const bf16_t *)qkv_dev, (const bf16_t *)dout_dev, (bf16_t *)dqkv_dev, T, heads, causal, key_mask_dev);
     return launch_check("sgclip_attention_bwd");

@@ -1246,7 +1246,7 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
         a.need_hi = mclass_hi[k];
         const int lds_bytes = crop_lds_m(S, mksx[k], mksy[k], mwnc[k], bpw * BR).total;
         auto go = [&](auto kernel) {
-            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+            (void)lds_attr((const void *)kernel, LDS_LIMIT);
             hipLaunchKernelGGL(kernel, grid, dim3(NTM), lds_bytes, stream, a);
         };
         const int blocks = (S + 15) / 16;
@@ -1266,7 +1266,7 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
         a.need_hi = k < 4 ? class_hi[k] : INT32_MAX;
         const int lds_bytes = crop_lds(S, ksx[k], ksy[k], wnc[k], bpw * BR).total;
         auto go = [&](auto kernel) {
-            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+            (void)lds_attr((const void *)kernel, LDS_LIMIT);
             hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, a);
         };
         if (k == 4) {

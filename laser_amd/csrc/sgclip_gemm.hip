@@ -1515,15 +1515,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_kernel(GemmArgs g) {
                                                   lane);
 }
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel instead of before every launch
-static void lds_attr_once(const void *fn, int bytes) {
-    static std::mutex mu;
-    static std::vector<const void *> done;
-    std::lock_guard<std::mutex> lock(mu);
-    if (std::find(done.begin(), done.end(), fn) != done.end()) return;
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    done.push_back(fn);
-}
+// dynamic LDS limit of `fn` on the current device (see lds_attr); a refusal surfaces through launch_check as the
+// launch failure that follows it
+static void lds_attr_once(const void *fn, int bytes) { (void)lds_attr(fn, bytes); }
 
 static int gemm_variant() {
     static int v = -1;
@@ -1587,15 +1581,12 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
         g.tiles_n = ceil_div(g.N, 256);
         g.col_group = splits == 1 ? pipe64_col_group(g.tiles_m, g.tiles_n, g.K) : 0;
         if constexpr (EPI != SGCLIP_EPI_F32_ATOMIC) {
-            static int persist = -1, cus = 0;
+            static int persist = -1;
             if (persist < 0) {
                 const char *e = getenv("SGCLIP_GEMM_PERSISTENT");
                 persist = e ? atoi(e) : 2;
-                int dev = 0;
-                if (hipGetDevice(&dev) != hipSuccess ||
-                    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-                    cus = 256;
             }
+            const int cus = device_cus();
             // Mode 2 (default): one workgroup per tile for deep reductions with many tile columns (the ViT-L q/k/v, fc1
             // and fc2 shapes).  Workgroups dispatched per tile run in step, so all epilogues of a round coincide and the
             // main loops never compete with result stores for the fabric (24.5 us per tile against 26.6 us for
@@ -1621,32 +1612,17 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
     } else if ((variant == 4 || (variant >= 5 && big_tiles >= 512)) && g.M > 128 && g.K % 32 == 0 && g.N >= 256) {
         g.tiles_m = ceil_div(g.M, 256);
         g.tiles_n = ceil_div(g.N, 256);
-        static bool attr_big = false;
-        if (!attr_big) {
-            (void)hipFuncSetAttribute((const void *)gemm_big_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      BIG_SLOTS * BIG_SLOT);
-            attr_big = true;
-        }
+        lds_attr_once((const void *)gemm_big_kernel<EPI>, BIG_SLOTS * BIG_SLOT);
         hipLaunchKernelGGL(gemm_big_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n, gy), dim3(512), BIG_SLOTS * BIG_SLOT,
                            stream, g);
     } else if (use32 && g.M > 128 && g.K % 32 == 0) {
         g.tiles_m = ceil_div(g.M, RING_BM);
-        static bool attr_set32 = false;
-        if (!attr_set32) {
-            (void)hipFuncSetAttribute((const void *)gemm_ring32_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      R32_SLOTS * R32_SLOT);
-            attr_set32 = true;
-        }
+        lds_attr_once((const void *)gemm_ring32_kernel<EPI>, R32_SLOTS * R32_SLOT);
         hipLaunchKernelGGL(gemm_ring32_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n, gy), dim3(512), R32_SLOTS * R32_SLOT,
                            stream, g);
     } else if (gemm_variant() >= 1 && g.M > 128) {
         g.tiles_m = ceil_div(g.M, RING_BM);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)gemm_ring_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      RING_SLOTS * RING_SLOT);
-            attr_set = true;
-        }
+        lds_attr_once((const void *)gemm_ring_kernel<EPI>, RING_SLOTS * RING_SLOT);
         hipLaunchKernelGGL(gemm_ring_kernel<EPI>, dim3((unsigned)g.tiles_m * g.tiles_n, gy), dim3(512), RING_SLOTS * RING_SLOT,
                            stream, g);
     } else {
@@ -1873,12 +1849,8 @@ extern "C" int sgclip_gemm_tn_bf16(const void *A_dev, int lda, const void *B_dev
         const char *e = getenv("SGCLIP_TN_WGS");
         target = e ? atoi(e) : 256;
     }
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P64_SLOT);
-        (void)hipFuncSetAttribute((const void *)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P64_SLOT);
-        attr = true;
-    }
+    if (!lds_attr((const void *)gemm_tn_kernel<true>, 2 * P64_SLOT) || !lds_attr((const void *)gemm_tn_kernel<false>, 2 * P64_SLOT))
+        return SGCLIP_ELAUNCH;
     const long tiles = (long)g.tiles_m * g.tiles_n;
     KernelTimer timer(TK_GEMM0 + SGCLIP_EPI_F32_ATOMIC, 2.0 * M * N * Kd, stream);
     // Whole 64-row stages go to the kernel that assumes them (every slice a multiple of 64 rows, at least two stages);

@@ -319,11 +319,7 @@ extern "C" int sgclip_qkv_attention(const void *x_dev, int ldx, const void *w_qk
         set_error("sgclip_qkv_attention: problem too large");
         return SGCLIP_EINVAL;
     }
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)qkv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QA_SLOT);
-        attr = true;
-    }
+    if (!lds_attr((const void *)qkv_attn_kernel, 2 * QA_SLOT)) return SGCLIP_ELAUNCH;
     KernelTimer timer(TK_GEMM0 + SGCLIP_EPI_BIAS_BF16, 2.0 * g.M * 3.0 * d * d + 4.0 * n_seq * heads * (double)T * T * 64, stream);
     hipLaunchKernelGGL(qkv_attn_kernel, dim3((unsigned)grid), dim3(512), 2 * QA_SLOT, stream, g);
     return launch_check("sgclip_qkv_attention");

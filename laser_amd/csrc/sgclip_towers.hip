@@ -14,6 +14,9 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 namespace sgclip {
@@ -34,6 +37,38 @@ int launch_check(const char *what) {
         return SGCLIP_ELAUNCH;
     }
     return SGCLIP_OK;
+}
+
+bool lds_attr(const void *fn, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, int> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find({fn, dev});
+    if (it != done.end() && it->second >= bytes) return true;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        // HIP's last-error state keeps the failure, so a launch_check() behind the skipped launch reports it too
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) on device %d: %s", bytes, dev, hipGetErrorString(e));
+        return false;
+    }
+    done[{fn, dev}] = bytes;
+    return true;
+}
+
+int device_cus() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+    return n;
 }
 
 // ---- opt-in kernel timing ---------------------------------------------------

@@ -37,7 +37,7 @@ def transpose_bf16(x: torch.Tensor, ld_out: Optional[int] = None) -> torch.Tenso
     R, Cc = x.shape
     ld_out = ld_out or R
     out = torch.empty((Cc, ld_out), dtype=BF16, device=x.device)
-    _lib.check(_lib.load().sgclip_transpose_bf16(x.data_ptr(), x.stride(0), R, Cc, out.data_ptr(), ld_out, _stream()))
+    _lib.check(_lib.load().sgclip_transpose_bf16(x.data_ptr(), x.stride(0), R, Cc, out.data_ptr(), ld_out, _stream(x)))
     return out
 
 
@@ -47,28 +47,28 @@ def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     M, N = x.shape
     if out is None:
         out = torch.zeros(N, dtype=F32, device=x.device)
-    _lib.check(_lib.load().sgclip_colsum(x.data_ptr(), _dtype_code(x), x.stride(0), M, N, out.data_ptr(), _stream()))
+    _lib.check(_lib.load().sgclip_colsum(x.data_ptr(), _dtype_code(x), x.stride(0), M, N, out.data_ptr(), _stream(x)))
     return out
 
 
 def quick_gelu(u: torch.Tensor) -> torch.Tensor:
     assert u.dtype == BF16 and u.is_contiguous()
     g = torch.empty_like(u)
-    _lib.check(_lib.load().sgclip_quick_gelu(u.data_ptr(), g.data_ptr(), u.numel(), _stream()))
+    _lib.check(_lib.load().sgclip_quick_gelu(u.data_ptr(), g.data_ptr(), u.numel(), _stream(u)))
     return g
 
 
 def quick_gelu_bwd(u: torch.Tensor, dg: torch.Tensor) -> torch.Tensor:
     assert u.dtype == BF16 and dg.dtype == BF16 and u.is_contiguous() and dg.is_contiguous() and u.shape == dg.shape
     du = torch.empty_like(u)
-    _lib.check(_lib.load().sgclip_quick_gelu_bwd(u.data_ptr(), dg.data_ptr(), du.data_ptr(), u.numel(), _stream()))
+    _lib.check(_lib.load().sgclip_quick_gelu_bwd(u.data_ptr(), dg.data_ptr(), du.data_ptr(), u.numel(), _stream(u)))
     return du
 
 
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     assert x.dtype == F32 and x.is_contiguous()
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
-    _lib.check(_lib.load().sgclip_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()))
+    _lib.check(_lib.load().sgclip_cast_f32_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream(x)))
     return y
 
 
@@ -81,7 +81,7 @@ def cast_bf16_colsum(x: torch.Tensor, colsum_out: torch.Tensor) -> torch.Tensor:
         return cast_bf16(x)
     assert colsum_out.dtype == F32 and colsum_out.is_contiguous() and colsum_out.numel() == N
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
-    _lib.check(_lib.load().sgclip_cast_colsum_f32_bf16(x.data_ptr(), y.data_ptr(), M, N, colsum_out.data_ptr(), _stream()))
+    _lib.check(_lib.load().sgclip_cast_colsum_f32_bf16(x.data_ptr(), y.data_ptr(), M, N, colsum_out.data_ptr(), _stream(x)))
     return y
 
 
@@ -98,7 +98,7 @@ def fc2_dgrad_through_gelu(dy: torch.Tensor, w_t: torch.Tensor, u: torch.Tensor,
     du = torch.empty_like(u)
     _lib.check(_lib.load().sgclip_gemm_mulgelugrad_bf16(dy.data_ptr(), dy.stride(0), w_t.data_ptr(), w_t.stride(0), du.data_ptr(),
                                                         N, M, N, K, zero_bias.data_ptr(), u.data_ptr(), colsum_out.data_ptr(),
-                                                        _stream()))
+                                                        _stream(dy)))
     return du
 
 
@@ -113,7 +113,7 @@ def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor
     assert dx.dtype == F32 and dx.is_contiguous() and dx.shape == x.shape
     _lib.check(_lib.load().sgclip_layernorm_bwd(x.data_ptr(), x.stride(0), rows, d, w.data_ptr(), eps, dy.data_ptr(),
                                                 _dtype_code(dy), dx.data_ptr(), 1 if accumulate else 0, dw.data_ptr(),
-                                                db.data_ptr(), _stream()))
+                                                db.data_ptr(), _stream(x)))
     return dx
 
 
@@ -123,7 +123,7 @@ def attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, n_seq: int, T: int, hea
     assert qkv.shape == (n_seq * T, 3 * heads * 64) and dout.shape == (n_seq * T, heads * 64)
     dqkv = torch.empty_like(qkv)
     _lib.check(_lib.load().sgclip_attention_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), n_seq, T, heads,
-                                                1 if causal else 0, _ptr(key_mask), _stream()))
+                                                1 if causal else 0, _ptr(key_mask), _stream(qkv)))
     return dqkv
 
 
@@ -139,7 +139,7 @@ def matmul_f32(A: torch.Tensor, B: torch.Tensor, transA: bool = False, transB: b
         out = torch.empty((M, N), dtype=F32, device=A.device)
     _lib.check(_lib.load().sgclip_matmul_f32(A.data_ptr(), A.stride(0), 1 if transA else 0, B.data_ptr(), B.stride(0),
                                              1 if transB else 0, out.data_ptr(), out.stride(0), M, N, K, float(alpha),
-                                             1 if accumulate else 0, _stream()))
+                                             1 if accumulate else 0, _stream(A)))
     return out
 
 
@@ -147,7 +147,7 @@ def dot_f32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """0-dim f32 <a, b>."""
     assert a.dtype == F32 and b.dtype == F32 and a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
     out = torch.zeros((), dtype=F32, device=a.device)
-    _lib.check(_lib.load().sgclip_dot_f32(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), _stream()))
+    _lib.check(_lib.load().sgclip_dot_f32(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), _stream(a)))
     return out
 
 
@@ -155,14 +155,14 @@ def prob_bwd(probs: torch.Tensor, dprobs: torch.Tensor, mode: int) -> torch.Tens
     assert probs.dtype == F32 and probs.is_contiguous() and dprobs.is_contiguous() and probs.shape == dprobs.shape
     K, N = probs.shape
     dl = torch.empty_like(probs)
-    _lib.check(_lib.load().sgclip_prob_bwd(probs.data_ptr(), dprobs.data_ptr(), K, N, mode, dl.data_ptr(), _stream()))
+    _lib.check(_lib.load().sgclip_prob_bwd(probs.data_ptr(), dprobs.data_ptr(), K, N, mode, dl.data_ptr(), _stream(probs)))
     return dl
 
 
 def normalize_rows(x: torch.Tensor) -> torch.Tensor:
     assert x.dtype == F32 and x.is_contiguous() and x.dim() == 2
     y = torch.empty_like(x)
-    _lib.check(_lib.load().sgclip_normalize_rows(x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), _stream()))
+    _lib.check(_lib.load().sgclip_normalize_rows(x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), _stream(x)))
     return y
 
 
@@ -170,7 +170,7 @@ def normalize_bwd(x: torch.Tensor, dxhat: torch.Tensor) -> torch.Tensor:
     assert x.dtype == F32 and x.is_contiguous() and dxhat.is_contiguous() and x.shape == dxhat.shape
     dx = torch.empty_like(x)
     _lib.check(_lib.load().sgclip_normalize_bwd(x.data_ptr(), dxhat.data_ptr(), x.shape[0], x.shape[1], dx.data_ptr(),
-                                                _stream()))
+                                                _stream(x)))
     return dx
 
 
@@ -179,7 +179,7 @@ def segment_mean_bwd(dmean: torch.Tensor, seg: torch.Tensor, inv_count: torch.Te
     K, G = dmean.shape
     out = torch.empty((K, N), dtype=F32, device=dmean.device)
     _lib.check(_lib.load().sgclip_segment_mean_bwd(dmean.data_ptr(), seg.data_ptr(), inv_count.data_ptr(), K, N, G,
-                                                   out.data_ptr(), _stream()))
+                                                   out.data_ptr(), _stream(dmean)))
     return out
 
 
@@ -189,14 +189,14 @@ def embed_text(table: torch.Tensor, pos: torch.Tensor, ids: torch.Tensor) -> tor
     K, T = ids.shape
     d = table.shape[1]
     x = torch.empty((K * T, d), dtype=F32, device=table.device)
-    _lib.check(_lib.load().sgclip_embed_text(table.data_ptr(), pos.data_ptr(), ids.data_ptr(), K, T, d, x.data_ptr(), _stream()))
+    _lib.check(_lib.load().sgclip_embed_text(table.data_ptr(), pos.data_ptr(), ids.data_ptr(), K, T, d, x.data_ptr(), _stream(table)))
     return x
 
 
 def embed_cls(cls: torch.Tensor, pos: torch.Tensor, x: torch.Tensor, n_images: int, T: int):
     """Writes cls + pos[0] into row 0 of every image of x (f32 [n_images*T, d])."""
     d = x.shape[1]
-    _lib.check(_lib.load().sgclip_embed_cls(cls.data_ptr(), pos.data_ptr(), n_images, T, d, x.data_ptr(), _stream()))
+    _lib.check(_lib.load().sgclip_embed_cls(cls.data_ptr(), pos.data_ptr(), n_images, T, d, x.data_ptr(), _stream(x)))
 
 
 def rows_scatter_add(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor):
@@ -204,7 +204,7 @@ def rows_scatter_add(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor):
     assert src.dtype == F32 and dst.dtype == F32 and src.is_contiguous() and dst.is_contiguous()
     assert idx.dtype == torch.int32 and idx.numel() == src.shape[0] and src.shape[1] == dst.shape[1]
     _lib.check(_lib.load().sgclip_rows_scatter_add(src.data_ptr(), idx.data_ptr(), src.shape[0], src.shape[1], dst.data_ptr(),
-                                                   _stream()))
+                                                   _stream(src)))
 
 
 def adamw(param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float,
@@ -212,7 +212,7 @@ def adamw(param: torch.Tensor, grad: torch.Tensor, m: torch.Tensor, v: torch.Ten
     for t in (param, grad, m, v):
         assert t.dtype == F32 and t.is_contiguous() and t.numel() == param.numel()
     _lib.check(_lib.load().sgclip_adamw(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), param.numel(), lr,
-                                        beta1, beta2, eps, weight_decay, step, _stream()))
+                                        beta1, beta2, eps, weight_decay, step, _stream(param)))
 
 
 # -- linear layers on the MFMA GEMM ---------------------------------------------------------
@@ -235,7 +235,7 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] 
             and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
         # both operands as they lie in memory (rows = the reduction index); fragments are transposed on the LDS read
         _lib.check(_lib.load().sgclip_gemm_tn_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(),
-                                                   out.stride(0), dy.shape[1], x.shape[1], M, _stream()))
+                                                   out.stride(0), dy.shape[1], x.shape[1], M, _stream(dy)))
         return out
     Mp = pad64(M)
     dyt = transpose_bf16(dy, Mp)

@@ -289,8 +289,15 @@ def gemm_bf16(A: torch.Tensor, W: torch.Tensor, C_out: torch.Tensor, epilogue: i
     lib = _lib.load()
     M, K = A.shape
     N = W.shape[0]
+    if aux is not None and epilogue != _lib.EPI_PATCH_F32:
+        # the second operand of an epilogue is addressed with C's row stride: residual (f32, read), pre-activation
+        # (bf16, read) or activation (bf16, WRITTEN by EPI_BIAS_GELU_BOTH_BF16)
+        want = torch.float32 if epilogue == _lib.EPI_BIAS_RESID_F32 else torch.bfloat16
+        if aux.dtype != want or aux.dim() != 2 or aux.stride(1) != 1 or aux.stride(0) != C_out.stride(0) or aux.shape != C_out.shape:
+            raise ValueError(f"epilogue {epilogue}: aux must be {want} of C's shape and row stride, got {aux.dtype} "
+                             f"{tuple(aux.shape)} stride {aux.stride()} for C {tuple(C_out.shape)} stride {C_out.stride()}")
     _lib.check(lib.sgclip_gemm_bf16(A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0), C_out.data_ptr(),
-                                    C_out.stride(0), M, N, K, epilogue, _ptr(bias), _ptr(aux), aux_rows, _stream()))
+                                    C_out.stride(0), M, N, K, epilogue, _ptr(bias), _ptr(aux), aux_rows, _stream(A)))
     return C_out
 
 

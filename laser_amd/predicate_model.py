@@ -108,6 +108,11 @@ class DeviceInputs:
         self.masks, self.mask_off, self.mask_ndim = masks, mask_off, mask_ndim
         self.mask_hw = mask_hw    # (H, W) per mask; forward() checks each against its frame
         self.unpacked = unpacked  # laser_amd.masks.UnpackedMasks when the masks arrived bit-packed
+        # set by laser_amd.staging.InputStager: the event behind the uploads, the buffer set to hand back, and tensors
+        # that were allocated under the copy stream
+        self.ready_event = None
+        self.slot = None
+        self.transient = []
 
     def bbox_dicts(self):
         """Boxes of bit-packed masks, computed on the GPU, in the reference's dict form
@@ -152,12 +157,12 @@ class PredicateModel(nn.Module):
         # objects whose mean category probability lies within the bf16 towers' error of the boundary between the
         # `topk_cate`-th and the next candidate of a name the predicates use are scored again in fp32
         # (laser_amd/rescore.py) before ranking.  rank_guard_cos_err: bound on the error of a cosine similarity through
-        # the bf16 towers; rank_exact_cos_err: the same for the fp32 path (two fp32 evaluations of a tower that add in
-        # different orders differ by this much).  What the guard did in the last forward() is in `ranking_report`;
+        # the bf16 towers; rank_exact_cos_err: the same for the fp32 path (measured against the CPU oracle: per-object
+        # means agree to 1e-8 .. 4e-7 absolute at logit scale 100, i.e. cosines to about 1e-8).  What the guard did in the last forward() is in `ranking_report`;
         # boundaries that stay closer than the fp32 bound are listed there with decided=False and warned about.
         self.rank_guard = True
         self.rank_guard_cos_err = 2.5e-3
-        self.rank_exact_cos_err = 4e-6
+        self.rank_exact_cos_err = 1e-7
         self.ranking_report: List[dict] = []
         self._exact_towers: Dict = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed_weights())
@@ -311,6 +316,17 @@ class PredicateModel(nn.Module):
             self._pinned_done("masks")
         return DeviceInputs(frames, frame_off, frame_hw, masks, mask_off, mask_ndim, mask_hw=mask_hw)
 
+    def stage_inputs_async(self, batched_videos, batched_masks, depth: int = 2):
+        """`stage_inputs` off the caller's thread and off the scoring stream: returns at once with a handle that
+        `forward(device_inputs=...)` accepts.  A worker thread packs the arrays into pinned memory and queues the
+        copies on a HIP stream of its own, so the upload of clip n + 1 runs under the scoring of clip n
+        (laser_amd/staging.py).  Submit at most `depth - 1` clips ahead of the forward() calls; pass each handle to
+        exactly one forward()."""
+        if getattr(self, "_stager", None) is None:
+            from .staging import InputStager
+            self._stager = InputStager(self, depth=depth)
+        return self._stager.submit(batched_videos, batched_masks)
+
     def _pinned(self, name: str, nbytes: int) -> torch.Tensor:
         """A pinned host staging buffer of at least `nbytes`, free to be overwritten (the copy that last read it
         has finished)."""
@@ -356,9 +372,11 @@ class PredicateModel(nn.Module):
         step, so the unary tower and the two halves of the pair tower are queued beside the category tower; the
         tails and kernel boundaries of one launch sequence are then filled by the others.
         SGCLIP_CONCURRENT_TOWERS=0 keeps everything on the caller's stream."""
+        if not getattr(self, "concurrent_towers", True):
+            return []
         if getattr(self, "_streams", None) is None:
             on = os.environ.get("SGCLIP_CONCURRENT_TOWERS", "1") != "0"
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)] if on else []
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(4)] if on else []
         return self._streams
 
     def _encode_images(self, prefix: str, patches: torch.Tensor, n: int) -> torch.Tensor:
@@ -464,12 +482,35 @@ class PredicateModel(nn.Module):
                 batched_object_ids, batched_unary_kws, batched_binary_kws, batched_obj_pairs, batched_video_splits,
                 batched_binary_predicates, unary_segment_size=None, binary_segment_size=None, alpha=0.5,
                 white_alpha=0.8, topk_cate=3, dummy_str="$$$", multi_class=False, output_logit=False,
-                output_embeddings=False, device_inputs: Optional[DeviceInputs] = None, allow_dummy_pair: bool = True):
+                output_embeddings=False, device_inputs=None, allow_dummy_pair: bool = True):
         """Reference signature (llava_clip_model_v3.py:86-107) plus two optional extras: `device_inputs`
-        (frames / masks already staged in HBM) and `allow_dummy_pair` (False: a call without any pair
+        (frames / masks already staged in HBM: a DeviceInputs from `stage_inputs`, or the handle
+        `stage_inputs_async` returned) and `allow_dummy_pair` (False: a call without any pair
         scores no whole-frame stand-in, for shards of a larger call that does have pairs).
         Gradients flow to the CLIP parameters when they are trainable (`enable_training`) and autograd
         is enabled; otherwise the call runs under torch.no_grad()."""
+        if device_inputs is not None and hasattr(device_inputs, "result"):
+            device_inputs = device_inputs.result()
+        slot = getattr(device_inputs, "slot", None)
+        main_stream = torch.cuda.current_stream(self.device)
+        if device_inputs is not None and device_inputs.ready_event is not None:
+            main_stream.wait_event(device_inputs.ready_event)
+            for t in device_inputs.transient:
+                t.record_stream(main_stream)
+        try:
+            return self._forward(batched_video_ids, batched_videos, batched_masks, batched_bboxes, batched_names,
+                                 batched_object_ids, batched_unary_kws, batched_binary_kws, batched_obj_pairs,
+                                 batched_video_splits, batched_binary_predicates, alpha, white_alpha, topk_cate, dummy_str,
+                                 multi_class, output_logit, output_embeddings, device_inputs, allow_dummy_pair)
+        finally:
+            if slot is not None:
+                device_inputs.slot = None
+                slot.release(main_stream)     # every side stream has been joined into main_stream by now
+
+    def _forward(self, batched_video_ids, batched_videos, batched_masks, batched_bboxes, batched_names,
+                 batched_object_ids, batched_unary_kws, batched_binary_kws, batched_obj_pairs, batched_video_splits,
+                 batched_binary_predicates, alpha, white_alpha, topk_cate, dummy_str, multi_class, output_logit,
+                 output_embeddings, device_inputs, allow_dummy_pair):
         dev = self.device
         B = len(batched_video_ids)
         grad_mode = self._grad_mode()
@@ -485,10 +526,24 @@ class PredicateModel(nn.Module):
         dummy_terms: List[torch.Tensor] = []
         self.ranking_report = []
 
-        # Step 1: text features of the three vocabularies (:137-186)
-        name_feats = [self._text_features("clip_cate_model", n) for n in batched_names]
-        unary_feats = [self._text_features("clip_unary_model", n) for n in batched_unary_kws]
-        binary_feats = [self._text_features("clip_binary_model", n) for n in batched_binary_kws]
+        # Step 1: text features of the three vocabularies (:137-186).  They are needed at the similarity step only: on
+        # the inference path the text towers (small launches) are queued on a side stream beside the image towers.
+        side = [] if grad_mode else self._side_streams()
+        main_stream = torch.cuda.current_stream(self.device)
+
+        def all_text_features():
+            return ([self._text_features("clip_cate_model", n) for n in batched_names],
+                    [self._text_features("clip_unary_model", n) for n in batched_unary_kws],
+                    [self._text_features("clip_binary_model", n) for n in batched_binary_kws])
+        text_stream = side[3] if len(side) > 3 else None
+        if text_stream is not None:
+            text_stream.wait_stream(main_stream)
+            with torch.cuda.stream(text_stream):
+                name_feats, unary_feats, binary_feats = all_text_features()
+            for f in name_feats + unary_feats + binary_feats:
+                f.record_stream(main_stream)
+        else:
+            name_feats, unary_feats, binary_feats = all_text_features()
 
         # Step 2: object crop table (:188-217)
         splits = [0] + list(batched_video_splits)
@@ -496,8 +551,6 @@ class PredicateModel(nn.Module):
         if device_inputs is None:
             device_inputs = self.stage_inputs(batched_videos, batched_masks)
         di = device_inputs
-        side = [] if grad_mode else self._side_streams()
-        main_stream = torch.cuda.current_stream(self.device)
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(main_stream)     # frames and masks are in HBM: side streams start from here
         if batched_bboxes is None:                       # bit-packed masks: boxes come from the unpack kernel
@@ -556,6 +609,8 @@ class PredicateModel(nn.Module):
                 cate_feat = self._encode_images("clip_cate_model", patches, n_obj)
                 unary_feat = self._encode_images("clip_unary_model", patches, n_obj)
         sim_mode = _lib.SIM_LOGIT if output_logit else _lib.SIM_SOFTMAX
+        if text_stream is not None:
+            main_stream.wait_stream(text_stream)
 
         cate_out: Dict[int, object] = {v: {} for v in range(B)}
         unary_out: Dict[int, object] = {v: {} for v in range(B)}

@@ -32,6 +32,8 @@ class OraclePredicateModel:
         # True: the returned values stay attached to the autograd graph of the state-dict tensors
         # (fp32 autograd reference for the train step, scripts/train_sgclip.py:682-694, 877-890)
         self.grad = False
+        # True: the resize runs in Pillow's C code, as in the reference (CPU timing); False: the numpy restatement
+        self.pillow = False
 
     # ----- helpers ---------------------------------------------------------
     def _text(self, sd, kws):
@@ -44,7 +46,7 @@ class OraclePredicateModel:
         return fn(sd, self.cfg, px)
 
     def _pixels(self, crops: List[np.ndarray]) -> torch.Tensor:
-        return torch.from_numpy(np.stack([resample_ref.preprocess(c, self.S) for c in crops]))
+        return torch.from_numpy(np.stack([resample_ref.preprocess(c, self.S, pillow=self.pillow) for c in crops]))
 
     # ----- forward ---------------------------------------------------------
     def forward(self, *args, **kwargs):

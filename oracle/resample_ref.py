@@ -118,9 +118,20 @@ def normalize_lut(mean=CLIP_MEAN, std=CLIP_STD) -> np.ndarray:
     return np.stack([(x - m[c]) / s[c] for c in range(3)]).astype(np.float32)
 
 
-def preprocess(img: np.ndarray, S: int, mean=CLIP_MEAN, std=CLIP_STD) -> np.ndarray:
-    """u8[h,w,3] crop -> f32[3,S,S] pixel_values."""
-    u8 = resize_center_crop_u8(img, S)
+def resize_center_crop_pillow(img: np.ndarray, S: int) -> np.ndarray:
+    """The same u8[S,S,3] through Pillow's own C resampler, as the reference's processor runs it
+    (transformers/image_transforms.py:367); bit-equal to `resize_center_crop_u8` (tests/test_oracle.py)."""
+    from PIL import Image
+    h, w, _ = img.shape
+    new_h, new_w = resize_output_size(h, w, S)
+    top, left = (new_h - S) // 2, (new_w - S) // 2
+    full = np.asarray(Image.fromarray(np.ascontiguousarray(img)).resize((new_w, new_h), resample=Image.BICUBIC))
+    return np.ascontiguousarray(full[top:top + S, left:left + S])
+
+
+def preprocess(img: np.ndarray, S: int, mean=CLIP_MEAN, std=CLIP_STD, pillow: bool = False) -> np.ndarray:
+    """u8[h,w,3] crop -> f32[3,S,S] pixel_values.  pillow: resize with Pillow itself instead of the restatement."""
+    u8 = resize_center_crop_pillow(img, S) if pillow else resize_center_crop_u8(img, S)
     lut = normalize_lut(mean, std)
     out = np.empty((3, S, S), dtype=np.float32)
     for c in range(3):

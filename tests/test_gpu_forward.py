@@ -287,9 +287,9 @@ def test_concurrent_towers_give_the_single_stream_result():
                         min_box=12, max_box=90)
     kw = b.forward_kwargs()
     assert len(kw["batched_obj_pairs"]) >= 1024
-    assert len(model._side_streams()) == 3
+    assert len(model._side_streams()) == 4    # unary tower, two pair halves, text towers
     runs = [model(**kw) for _ in range(2)]
-    model._streams = []                       # single stream
+    model.concurrent_towers = False           # single stream
     ref = model(**kw)
     torch.cuda.synchronize()
     for got in runs:

@@ -62,6 +62,12 @@ def test_gemm_epilogues(dev):
     ops.gemm_bf16(A, W, out, _lib.EPI_BIAS_GELU_BF16, bias=bias)
     z = ref + bias
     assert (out.float() - z * torch.sigmoid(1.702 * z)).abs().max().item() < 3e-2
+    # pre-activation and activation together (train step)
+    g = torch.empty_like(out)
+    ops.gemm_bf16(A, W, out, _lib.EPI_BIAS_GELU_BOTH_BF16, bias=bias, aux=g)
+    assert (out.float() - z).abs().max().item() < 3e-2
+    u = out.float()
+    assert ((g.float() - u * torch.sigmoid(1.702 * u)).abs() <= (u * torch.sigmoid(1.702 * u)).abs() * 2.0 ** -7 + 1e-6).all()
     # residual, fp32 in place
     x0 = torch.randn(M, N, device=dev)
     x = x0.clone()
@@ -97,7 +103,14 @@ def test_gemm_many_tiles_per_workgroup(dev, M, N, K):
     ops.gemm_bf16(A, W, out, _lib.EPI_BIAS_GELU_BF16, bias=bias)
     z = ref + bias
     assert (out.float() - z * torch.sigmoid(1.702 * z)).abs().max().item() < 4e-2
-    del out, z
+    # both halves of the train step's MLP activation in one epilogue: C = bf16(u), aux = bf16(quick_gelu(C))
+    g = torch.empty_like(out)
+    ops.gemm_bf16(A, W, out, _lib.EPI_BIAS_GELU_BOTH_BF16, bias=bias, aux=g)
+    assert (out.float() - (ref + bias)).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    u = out.float()
+    assert torch.equal(g, (u * torch.sigmoid(1.702 * u)).to(torch.bfloat16)) or \
+        ((g.float() - u * torch.sigmoid(1.702 * u)).abs() <= (u * torch.sigmoid(1.702 * u)).abs() * 2.0 ** -7 + 1e-6).all()
+    del out, z, g, u
     x0 = torch.randn(M, N, device=dev)
     x = x0.clone()
     ops.gemm_bf16(A, W, x, _lib.EPI_BIAS_RESID_F32, bias=bias)

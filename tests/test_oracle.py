@@ -128,3 +128,11 @@ def test_oracle_forward_b32_matches_reference(name):
                                        atol=5e-5, rtol=1e-4)
             want_pairs = [(p[0], p[1], tuple(p[2])) for p in rec["binary_object_pairs"][str(v)]]
             assert want_pairs == list(out[4]["binary_object_pairs"][v])
+
+
+def test_pillow_path_of_the_oracle_equals_the_restatement():
+    pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(11)
+    for (h, w), S in (((90, 250), 224), ((300, 41), 64), ((224, 224), 224)):
+        img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        assert np.array_equal(resample_ref.preprocess(img, S, pillow=True), resample_ref.preprocess(img, S))
