@@ -79,7 +79,9 @@ typedef struct sgclip_crop {
  * copied in 16-byte pieces).
  * crops: host table; crops_dev: device buffer of n_crops entries that this
  * call fills (H2D copy on `stream`) unless crops_dev_ready != 0.
- * lut_dev: device scratch of SGCLIP_CROP_LUT_BYTES that this call fills.     */
+ * lut_dev: device buffer of SGCLIP_CROP_LUT_BYTES that this call fills from
+ * luts / norm_lut; with luts == norm_lut == NULL it already holds them (filled
+ * by an earlier call or by the caller: bytes 0..767 = luts, then norm_lut).  */
 #define SGCLIP_CROP_LUT_BYTES (768 + 768 * 4)
 int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_bytes, const uint8_t *masks_dev,
                            size_t masks_bytes, const sgclip_crop_t *crops, sgclip_crop_t *crops_dev,

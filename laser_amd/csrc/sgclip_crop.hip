@@ -1061,7 +1061,7 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
                                       void *out_dev, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n_crops == 0) return SGCLIP_OK;
-    if (!frames_dev || !crops || !crops_dev || !luts || !norm_lut || !lut_dev || !out_dev || n_crops < 0) {
+    if (!frames_dev || !crops || !crops_dev || (!luts != !norm_lut) || !lut_dev || !out_dev || n_crops < 0) {
         set_error("sgclip_crop_preprocess: null argument");
         return SGCLIP_EINVAL;
     }
@@ -1211,8 +1211,11 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
     }
     uint8_t *lut8_dev = (uint8_t *)lut_dev;
     float *norm_dev = (float *)(lut8_dev + 768);
-    hipError_t e = hipMemcpyAsync(lut8_dev, luts, 768, hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(norm_dev, norm_lut, 768 * 4, hipMemcpyHostToDevice, stream);
+    hipError_t e = hipSuccess;
+    if (luts) {   // null tables: lut_dev already holds them
+        e = hipMemcpyAsync(lut8_dev, luts, 768, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(norm_dev, norm_lut, 768 * 4, hipMemcpyHostToDevice, stream);
+    }
     if (e == hipSuccess && !crops_dev_ready)
         e = hipMemcpyAsync(crops_dev, crops, (size_t)n_crops * sizeof(sgclip_crop_t), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) {

@@ -3,6 +3,7 @@ stream; all arithmetic happens in libsgclip_hip.so)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -81,20 +82,44 @@ def crop_preprocess(frames: torch.Tensor, masks: Optional[torch.Tensor], entries
             out = torch.zeros((n * P, kpad), dtype=tdt, device=dev)
         else:
             out = torch.empty((n, 3, S, S), dtype=tdt, device=dev)
-    if entries_dev is None:
+    pinned = None
+    if entries_dev is None and n and PINNED_TABLES:
+        # the table goes up from pinned memory with an asynchronous copy queued on this stream: a copy from pageable
+        # memory may make the host wait for the work queued before it, which ends the host's run ahead of the GPU
+        if isinstance(entries, np.ndarray):
+            pinned = torch.from_numpy(entries.view(np.uint8).reshape(-1)).pin_memory()
+        else:
+            pinned = torch.frombuffer(bytearray(C.string_at(C.addressof(entries), n * C.sizeof(_lib.CropEntry))),
+                                      dtype=torch.uint8).pin_memory()
+        entries_dev = pinned.to(dev, non_blocking=True)
+        entries_dev_ready = True
+    elif entries_dev is None:
         entries_dev = torch.empty(max(n, 1) * C.sizeof(_lib.CropEntry), dtype=torch.uint8, device=dev)
-    lut_dev = torch.empty(_lib.CROP_LUT_BYTES, dtype=torch.uint8, device=dev)
-    luts = np.ascontiguousarray(blend_luts(alpha, white_alpha))
-    nlut = np.ascontiguousarray(normalize_lut(mean, std))
+    lut_dev = _crop_luts(dev, alpha, white_alpha, tuple(mean), tuple(std))
     rc = lib.sgclip_crop_preprocess(
         frames.data_ptr(), frames.numel() - PAD, _ptr(masks), (masks.numel() - PAD) if masks is not None else 0,
         _host_table_ptr(entries) if n else None, entries_dev.data_ptr(), 1 if entries_dev_ready else 0, n,
-        luts.ctypes.data, nlut.ctypes.data, lut_dev.data_ptr(), S, layout, patch, kpad, out_dtype, out.data_ptr(),
-        _stream(frames))
+        None, None, lut_dev.data_ptr(), S, layout, patch, kpad, out_dtype, out.data_ptr(), _stream(frames))
     _lib.check(rc)
-    # lut_dev / entries_dev are consumed asynchronously: keep them alive until the stream has run
-    out._sgclip_keepalive = (lut_dev, entries_dev)
+    # entries_dev is consumed asynchronously: keep it (and its pinned source) alive until the stream has run
+    out._sgclip_keepalive = (lut_dev, entries_dev, pinned)
     return out
+
+
+_LUT_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def _crop_luts(dev, alpha, white_alpha, mean, std) -> torch.Tensor:
+    """The crop kernel's level tables (blend tables, then the normalisation table) in HBM, uploaded once per
+    device and parameter set with a blocking copy, so that every later call on any stream finds them in place."""
+    key = (str(dev), float(alpha), float(white_alpha), mean, std)
+    t = _LUT_CACHE.get(key)
+    if t is None:
+        host = np.concatenate([blend_luts(alpha, white_alpha), normalize_lut(mean, std).view(np.uint8)])
+        assert host.size == _lib.CROP_LUT_BYTES
+        t = _LUT_CACHE[key] = torch.from_numpy(host).to(dev)
+        torch.cuda.current_stream(dev).synchronize()
+    return t
 
 
 def _host_table_ptr(entries) -> int:
@@ -105,6 +130,7 @@ def _host_table_ptr(entries) -> int:
     return C.addressof(entries)
 
 
+PINNED_TABLES = os.environ.get("SGCLIP_PINNED_TABLES", "1") != "0"   # 0: small tables go up from pageable memory (comparison)
 PAD = 16  # slack bytes appended to frame / mask buffers (the kernel copies rows in 16-byte pieces)
 
 
@@ -224,8 +250,15 @@ class Tower:
             input_ids = input_ids[:, :seq_len]
             attention_mask = None if attention_mask is None else attention_mask[:, :seq_len]
         K, T = input_ids.shape
-        ids = input_ids.to(self.device, torch.int32).contiguous()
-        am = None if attention_mask is None else attention_mask.to(self.device, torch.int32).contiguous()
+
+        def up(t):
+            # host tensors go up from pinned memory without blocking: a blocking copy waits for everything queued on
+            # the stream before it and ends the host's run ahead of the GPU
+            if t.device.type == "cpu" and PINNED_TABLES:
+                return t.to(torch.int32).contiguous().pin_memory().to(self.device, non_blocking=True)
+            return t.to(self.device, torch.int32).contiguous()
+        ids = up(input_ids)
+        am = None if attention_mask is None else up(attention_mask)
         need = lib.sgclip_text_workspace_bytes(C.byref(self.desc), K, T)
         ws = self._workspace(max(need, 256))
         out = torch.empty((K, self.cfg.proj), dtype=torch.float32, device=self.device)

@@ -537,7 +537,10 @@ class PredicateModel(nn.Module):
                     [self._text_features("clip_binary_model", n) for n in batched_binary_kws])
         text_stream = side[3] if len(side) > 3 else None
         if text_stream is not None:
-            text_stream.wait_stream(main_stream)
+            # no wait for the caller's stream: the text towers read token ids they upload themselves and the packed
+            # weights, which were uploaded with blocking copies when they were packed
+            if not ops.PINNED_TABLES:
+                text_stream.wait_stream(main_stream)
             with torch.cuda.stream(text_stream):
                 name_feats, unary_feats, binary_feats = all_text_features()
             for f in name_feats + unary_feats + binary_feats:
@@ -590,7 +593,108 @@ class PredicateModel(nn.Module):
                     group_of[oid] = len(oids)
                     oids.append(oid)
             seg_host = [group_of[oid] for (_, oid) in ids_lookup[vid]]
-            groups[vid] = (oids, torch.tensor(seg_host, dtype=torch.int32).to(dev), seg_host)
+            # from pinned memory and non-blocking: a blocking copy would make the host wait for everything queued on
+            # this stream, the previous call's kernels included, and end its run ahead of the GPU
+            seg_t = torch.tensor(seg_host, dtype=torch.int32)
+            seg_t = seg_t.pin_memory().to(dev, non_blocking=True) if ops.PINNED_TABLES else seg_t.to(dev)
+            groups[vid] = (oids, seg_t, seg_host)
+
+        need_ranking = batched_binary_predicates[0] is not None
+        pair_lookup: Dict[int, dict] = {v: {} for v in range(B)}
+        for (vid, fid, (a, b)) in batched_obj_pairs:
+            pair_lookup[vid].setdefault((a, b), []).append(fid)
+
+        def queue_pairs(obj_per_cate_all):
+            """Step 4 (:342-449): pair selection, the pair crop table, and the pair crops through the binary tower.
+            Returns (features, selected pairs per video, first column of each video, join): `join()` makes the caller's
+            stream wait for the side streams the tower was queued on."""
+            if not need_ranking:
+                selected = list(batched_obj_pairs)
+            else:
+                sel = set()
+                for bp_vid, preds in enumerate(batched_binary_predicates):
+                    cands = {nm: [oid for _, oid in lst[:topk_cate]] for nm, lst in obj_per_cate_all[bp_vid].items()}
+                    for (rel_name, from_name, to_name) in preds:
+                        if from_name in cands and to_name in cands:
+                            for a in cands[from_name]:
+                                for b in cands[to_name]:
+                                    if (a, b) in pair_lookup[bp_vid]:
+                                        for fid in pair_lookup[bp_vid][(a, b)]:
+                                            sel.add((bp_vid, fid, (a, b)))
+                selected = list(sel)
+            new_select: Dict[int, list] = {v: [] for v in range(B)}
+            for item in selected:
+                new_select[item[0]].append(item)
+            ordered = [item for v in range(B) for item in new_select[v]]       # crops grouped by video, as the towers see them
+            pair_table = np.zeros(len(ordered), dtype=CROP_DTYPE)
+            if ordered:
+                # the whole table at once: union of the two objects' boxes (:93-115), then the pixels that
+                # img[y1:y2, x1:x2] selects (:117)
+                pa = np.fromiter((obj_index[(vid, fid, pr[0])] for (vid, fid, pr) in ordered), dtype=np.int64, count=len(ordered))
+                pb = np.fromiter((obj_index[(vid, fid, pr[1])] for (vid, fid, pr) in ordered), dtype=np.int64, count=len(ordered))
+                ndim = np.asarray(di.mask_ndim)
+                if (ndim[pa] != 3).any() or (ndim[pb] != 3).any():
+                    raise IndexError("too many indices for array: pair masks must be 3-dimensional [H,W,1]")
+                fidx = np.fromiter((splits[vid] + fid for (vid, fid, _) in ordered), dtype=np.int64, count=len(ordered))
+                hw = np.asarray(di.frame_hw, dtype=np.int64)
+                Hs, Ws = hw[fidx, 0], hw[fidx, 1]
+                x1 = np.minimum(obj_box[pa, 0], obj_box[pb, 0]); y1 = np.minimum(obj_box[pa, 1], obj_box[pb, 1])
+                x2 = np.maximum(obj_box[pa, 2], obj_box[pb, 2]); y2 = np.maximum(obj_box[pa, 3], obj_box[pb, 3])
+
+                def clamp(v, n):                              # slice.indices() for a positive step
+                    return np.where(v < 0, np.maximum(v + n, 0), np.minimum(v, n))
+                xa, xb, ya, yb = clamp(x1, Ws), clamp(x2, Ws), clamp(y1, Hs), clamp(y2, Hs)
+                bad = np.nonzero((xb <= xa) | (yb <= ya))[0]
+                if len(bad):
+                    i = int(bad[0])
+                    raise ValueError(f"crop box [{y1[i]}:{y2[i]}, {x1[i]}:{x2[i]}] selects no pixel of a {Hs[i]}x{Ws[i]} "
+                                     f"frame: {batched_video_ids}")
+                moff = np.asarray(di.mask_off, dtype=np.int64)
+                pair_table["frame_off"] = np.asarray(di.frame_off, dtype=np.int64)[fidx]
+                pair_table["mask_a_off"], pair_table["mask_b_off"] = moff[pa], moff[pb]
+                pair_table["frame_w"], pair_table["frame_h"] = Ws, Hs
+                pair_table["x1"], pair_table["y1"], pair_table["x2"], pair_table["y2"] = xa, ya, xb, yb
+                pair_table["mode"] = _lib.CROP_PAIR
+            elif allow_dummy_pair:                          # default image when no pair exists (:416-420)
+                selected.append((0, -1, (-1, -1)))
+                new_select[0] = [(0, -1, (-1, -1))]
+                H, W = di.frame_hw[0]
+                pair_table = np.array([(di.frame_off[0], -1, -1, W, H, 0, 0, W, H, _lib.CROP_PLAIN, 0)], dtype=CROP_DTYPE)
+            pair_start = np.cumsum([0] + [len(new_select[v]) for v in range(B)])
+            n_pair = len(pair_table)
+            pair_feat, join = None, (lambda: None)
+            if n_pair:
+                if side and n_pair >= 1024:
+                    # queued from the point where the inputs were staged, not behind the object towers
+                    s_p0, s_p1 = side[1], side[2]
+                    P = self.cfg.n_patches
+                    half = n_pair // 2
+                    tower = self._packed()["clip_binary_model"][0]
+                    s_p0.wait_event(inputs_ready)
+                    with torch.cuda.stream(s_p0):
+                        ppatches = self._crops(di, pair_table, alpha, white_alpha)
+                        pair_feat = torch.empty((n_pair, self.cfg.proj), dtype=torch.float32, device=ppatches.device)
+                        s_p1.wait_stream(s_p0)
+                        tower.encode_images(ppatches[: half * P], half, out=pair_feat[:half], ws_slot=0)
+                    with torch.cuda.stream(s_p1):
+                        tower.encode_images(ppatches[half * P:], n_pair - half, out=pair_feat[half:], ws_slot=1)
+                    ppatches.record_stream(s_p1)
+                    pair_feat.record_stream(s_p1)
+                    pair_feat.record_stream(main_stream)
+
+                    def join(s_p0=s_p0, s_p1=s_p1):
+                        main_stream.wait_stream(s_p0)
+                        main_stream.wait_stream(s_p1)
+                else:
+                    ppatches = self._crops(di, pair_table, alpha, white_alpha)
+                    pair_feat = self._encode_images("clip_binary_model", ppatches, n_pair)
+            return pair_feat, new_select, pair_start, join
+
+        # Without predicates the selected pairs are the given ones (:368-370) and do not wait for the category scores, so
+        # the pair tower could be queued before the object towers (SGCLIP_PAIRS_FIRST=1); measured slower by 2 % (the
+        # pair table is then built on the host before the first launch), so the reference's order stays the default.
+        pairs_first = not need_ranking and os.environ.get("SGCLIP_PAIRS_FIRST", "0") != "0"
+        pairs_queued = queue_pairs(None) if pairs_first else None
 
         # Step 3: object crops through the category and unary towers (:233-339)
         cate_feat = unary_feat = None
@@ -617,7 +721,6 @@ class PredicateModel(nn.Module):
         cate_feats_out: Dict[int, object] = {v: {} for v in range(B)}
         unary_feats_out: Dict[int, object] = {v: {} for v in range(B)}
         obj_per_cate_all: Dict[int, dict] = {v: {} for v in range(B)}
-        need_ranking = batched_binary_predicates[0] is not None
         # the reference zips this loop with batched_binary_predicates (:233-238)
         for vid in range(min(B, len(batched_binary_predicates))):
             s, e = int(obj_start[vid]), int(obj_start[vid + 1])
@@ -671,88 +774,9 @@ class PredicateModel(nn.Module):
                     obj_per_cate_all[vid] = {nm: sorted([(float(host[r, g]), oid) for g, oid in enumerate(oids)], reverse=True)
                                              for r, nm in c_rows}
 
-        # Step 4: pair selection (:342-392)
-        pair_lookup: Dict[int, dict] = {v: {} for v in range(B)}
-        for (vid, fid, (a, b)) in batched_obj_pairs:
-            pair_lookup[vid].setdefault((a, b), []).append(fid)
-        if not need_ranking:
-            selected = list(batched_obj_pairs)
-        else:
-            sel = set()
-            for bp_vid, preds in enumerate(batched_binary_predicates):
-                cands = {nm: [oid for _, oid in lst[:topk_cate]] for nm, lst in obj_per_cate_all[bp_vid].items()}
-                for (rel_name, from_name, to_name) in preds:
-                    if from_name in cands and to_name in cands:
-                        for a in cands[from_name]:
-                            for b in cands[to_name]:
-                                if (a, b) in pair_lookup[bp_vid]:
-                                    for fid in pair_lookup[bp_vid][(a, b)]:
-                                        sel.add((bp_vid, fid, (a, b)))
-            selected = list(sel)
-        new_select: Dict[int, list] = {v: [] for v in range(B)}
-        for item in selected:
-            new_select[item[0]].append(item)
-        ordered = [item for v in range(B) for item in new_select[v]]       # crops grouped by video, as the towers see them
-        pair_table = np.zeros(len(ordered), dtype=CROP_DTYPE)
-        if ordered:
-            # the whole table at once: union of the two objects' boxes (:93-115), then the pixels that
-            # img[y1:y2, x1:x2] selects (:117)
-            pa = np.fromiter((obj_index[(vid, fid, pr[0])] for (vid, fid, pr) in ordered), dtype=np.int64, count=len(ordered))
-            pb = np.fromiter((obj_index[(vid, fid, pr[1])] for (vid, fid, pr) in ordered), dtype=np.int64, count=len(ordered))
-            ndim = np.asarray(di.mask_ndim)
-            if (ndim[pa] != 3).any() or (ndim[pb] != 3).any():
-                raise IndexError("too many indices for array: pair masks must be 3-dimensional [H,W,1]")
-            fidx = np.fromiter((splits[vid] + fid for (vid, fid, _) in ordered), dtype=np.int64, count=len(ordered))
-            hw = np.asarray(di.frame_hw, dtype=np.int64)
-            Hs, Ws = hw[fidx, 0], hw[fidx, 1]
-            x1 = np.minimum(obj_box[pa, 0], obj_box[pb, 0]); y1 = np.minimum(obj_box[pa, 1], obj_box[pb, 1])
-            x2 = np.maximum(obj_box[pa, 2], obj_box[pb, 2]); y2 = np.maximum(obj_box[pa, 3], obj_box[pb, 3])
-
-            def clamp(v, n):                              # slice.indices() for a positive step
-                return np.where(v < 0, np.maximum(v + n, 0), np.minimum(v, n))
-            xa, xb, ya, yb = clamp(x1, Ws), clamp(x2, Ws), clamp(y1, Hs), clamp(y2, Hs)
-            bad = np.nonzero((xb <= xa) | (yb <= ya))[0]
-            if len(bad):
-                i = int(bad[0])
-                raise ValueError(f"crop box [{y1[i]}:{y2[i]}, {x1[i]}:{x2[i]}] selects no pixel of a {Hs[i]}x{Ws[i]} "
-                                 f"frame: {batched_video_ids}")
-            moff = np.asarray(di.mask_off, dtype=np.int64)
-            pair_table["frame_off"] = np.asarray(di.frame_off, dtype=np.int64)[fidx]
-            pair_table["mask_a_off"], pair_table["mask_b_off"] = moff[pa], moff[pb]
-            pair_table["frame_w"], pair_table["frame_h"] = Ws, Hs
-            pair_table["x1"], pair_table["y1"], pair_table["x2"], pair_table["y2"] = xa, ya, xb, yb
-            pair_table["mode"] = _lib.CROP_PAIR
-        elif allow_dummy_pair:                          # default image when no pair exists (:416-420)
-            selected.append((0, -1, (-1, -1)))
-            new_select[0] = [(0, -1, (-1, -1))]
-            H, W = di.frame_hw[0]
-            pair_table = np.array([(di.frame_off[0], -1, -1, W, H, 0, 0, W, H, _lib.CROP_PLAIN, 0)], dtype=CROP_DTYPE)
-        pair_start = np.cumsum([0] + [len(new_select[v]) for v in range(B)])
-        n_pair = len(pair_table)
-        pair_feat = None
-        if n_pair:
-            if side and n_pair >= 1024:
-                # queued from the point where the inputs were staged, not behind the object towers
-                s_p0, s_p1 = side[1], side[2]
-                P = self.cfg.n_patches
-                half = n_pair // 2
-                tower = self._packed()["clip_binary_model"][0]
-                s_p0.wait_event(inputs_ready)
-                with torch.cuda.stream(s_p0):
-                    ppatches = self._crops(di, pair_table, alpha, white_alpha)
-                    pair_feat = torch.empty((n_pair, self.cfg.proj), dtype=torch.float32, device=ppatches.device)
-                    s_p1.wait_stream(s_p0)
-                    tower.encode_images(ppatches[: half * P], half, out=pair_feat[:half], ws_slot=0)
-                with torch.cuda.stream(s_p1):
-                    tower.encode_images(ppatches[half * P:], n_pair - half, out=pair_feat[half:], ws_slot=1)
-                ppatches.record_stream(s_p1)
-                pair_feat.record_stream(s_p1)
-                pair_feat.record_stream(main_stream)
-                main_stream.wait_stream(s_p0)
-                main_stream.wait_stream(s_p1)
-            else:
-                ppatches = self._crops(di, pair_table, alpha, white_alpha)
-                pair_feat = self._encode_images("clip_binary_model", ppatches, n_pair)
+        # Step 4: with predicates, the pairs among the best candidates of the names they mention (:342-392)
+        pair_feat, new_select, pair_start, join_pairs = pairs_queued if pairs_queued is not None else queue_pairs(obj_per_cate_all)
+        join_pairs()
 
         binary_out: List[object] = []
         pair_feats_out: Dict[int, object] = {v: torch.tensor([]) for v in range(B)}
