@@ -42,7 +42,8 @@ struct GemmArgs {
     int aux_rows;
     int tiles_m, tiles_n;
     int wide_epilogue;  // N % 8 == 0, ldc % 8 == 0 and C, bias, aux 16-byte aligned
-    int debug_mode;     // diagnostics only: 1 = skip epilogue stores, 2 = single K step, 5 = per-workgroup time trace
+    int debug_mode;     // diagnostics only: 1 = skip epilogue stores, 2 = single K step, 5 = per-workgroup time trace,
+                        // 6 = no epilogue, 7 / 8 / 10 = every tile reads the first tile's operands (both / A / W)
     float *colsum;      // EPI_MULGRAD through epilogue_passes: += column sums of C (null: none)
     int col_group;      // gemm_pipe64_kernel: tiles walk down the rows inside groups of this many tile columns (0: row major)
     int tn_gm, tn_gn, tn_upx;   // gemm_tn_kernel: tile group shape and (group, slice) units per XCD (tn_gm = 0: plain grid)
@@ -904,9 +905,13 @@ constexpr int P64P_STAGE = 4096;                                  // epilogue st
 constexpr int P64P_LDS = 2 * P64_SLOT + 8 * P64P_STAGE;           // 160 KiB
 
 // Eight-row epilogue passes of one wave's 64 x 128 block: pass (i, h) takes the rows 16 i + 4 fq + 2 h + {0, 1}.
-template <int EPI>
+// SPLIT: the staging rows lie in four separate 1 KiB pieces, 8 KiB apart (two rows each): the wave's own four DMA
+// pieces of an operand slot (gemm_pipe64q_kernel), so that the fetch it queues into that slot right after its epilogue can
+// only overwrite its own, finished staging.
+template <int EPI, bool SPLIT = false>
 __device__ __forceinline__ void epilogue_rows8(const GemmArgs &g, const f32x4 (&acc)[4][8], float *region, int mw, int nw,
                                                int lane) {
+#define ROWF(lr) (SPLIT ? ((lr) >> 1) * 2048 + ((lr) & 1) * 128 : (lr) * 128)   /* float offset of staging row lr */
     constexpr bool BF = epi_bf16_out<EPI>();
     constexpr int CPL = BF ? 8 : 4;                // columns per lane
     constexpr int LPR = 128 / CPL;                 // lanes per row
@@ -963,7 +968,7 @@ __device__ __forceinline__ void epilogue_rows8(const GemmArgs &g, const f32x4 (&
 #pragma unroll
         for (int j = 0; j < 8; j++)
 #pragma unroll
-            for (int e = 0; e < 2; e++) region[(fq * 2 + e) * 128 + ((j ^ fq) << 4) + frow] = acc[i][j][2 * h + e];
+            for (int e = 0; e < 2; e++) region[ROWF(fq * 2 + e) + ((j ^ fq) << 4) + frow] = acc[i][j][2 * h + e];
         wave_lds_sync();
         if (p == 0) {
             // the bias must have arrived before the first bounds branch (a fetch pending at a branch stays pending on the
@@ -978,7 +983,7 @@ __device__ __forceinline__ void epilogue_rows8(const GemmArgs &g, const f32x4 (&
             float v[CPL];
 #pragma unroll
             for (int q = 0; q < CPL; q += 4) {
-                const float4 t = *(const float4 *)(region + lr * 128 + ((cl + q) ^ ((lr >> 1) << 4)));
+                const float4 t = *(const float4 *)(region + ROWF(lr) + ((cl + q) ^ ((lr >> 1) << 4)));
                 v[q] = t.x + bias[q]; v[q + 1] = t.y + bias[q + 1]; v[q + 2] = t.z + bias[q + 2]; v[q + 3] = t.w + bias[q + 3];
             }
             [[maybe_unused]] const float4 sd = side[SIDE ? p % DEPTH : 0][SIDE ? rr : 0];
@@ -1077,7 +1082,32 @@ __device__ __forceinline__ void pipe64p_substep(f32x4 (&acc)[4][8], const bf16x8
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    if (DMA) pipe64p_fetch(src, wr_slot, wave);
+    if (DMA) {
+        // The eight fetches of a stage go out one per four MFMAs (issued back to back behind the barrier, the 64 fetches of
+        // the eight waves reach the CU's one address unit together).  The groups are fenced so that the compiler keeps the
+        // interleaving: the fetches are opaque assembly to it.  Worth 2 % on the q/k/v shape, nothing on the others.
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const bool isw = q >= 4;
+            p64_dma16(isw ? src.wbase : src.abase, isw ? src.voff_b : src.voff_a, (unsigned)(q & 3) * (isw ? src.stride_b : src.stride_a),
+                      isw ? src.max_b : src.max_a, (unsigned)(uintptr_t)LDS_PTR(wr_slot + (wave + 8 * q) * 1024));
+            if (READ) {   // twelve fragment reads over the eight groups: 2 1 2 1 2 1 2 1
+                const int r0 = (3 * q + 1) / 2, r1 = (3 * (q + 1) + 1) / 2;
+#pragma unroll
+                for (int r = r0; r < r1; r++) {
+                    if (r < 4) na[r] = *(const bf16x8 *)(rd_a + r * 2048);
+                    else nb[r - 4] = *(const bf16x8 *)(rd_b + (r - 4) * 2048);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int i = q >> 1, j = 4 * (q & 1) + t;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     if (READ) {
 #pragma unroll
         for (int i = 0; i < 4; i++) na[i] = *(const bf16x8 *)(rd_a + i * 2048);
@@ -1256,11 +1286,242 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64p_kernel(GemmArgs g) {
             g_pipe64_trace[16 * vb + 2] = t;
         }
         if (!more) break;   // (the wave's end waits for the fetches still in flight)
-        after_full_tile = m0 + 256 <= g.M && n0 + 256 <= g.N && (g.debug_mode == 0 || g.debug_mode == 5) && !(EPI == EPI_MULGRAD && g.colsum);
+        after_full_tile = m0 + 256 <= g.M && n0 + 256 <= g.N && (g.debug_mode == 0 || g.debug_mode == 5 || g.debug_mode == 7 || g.debug_mode == 8 || g.debug_mode == 10) && !(EPI == EPI_MULGRAD && g.colsum);
         vb = vb_next;
         m0 = m1;
         n0 = n1;
         par = (par + ns) & 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------
+// The persistent kernel with the A operand fetched TWO stages ahead.
+//
+// Measured on the tower shapes (262 144 rows): when every tile reads the first tile's A rows (all L2 hits) the launches
+// take 11-19 % less time, with the first tile's W rows nothing changes: the weights are hot in every XCD's L2, the
+// activation stream comes from HBM, and a fetch that is issued one stage (about 1.5 us) before its barrier has the
+// slowest of its 512 cache lines still on the way when the workgroup gets there.  The 160 KiB of LDS hold five operand
+// stages of 32 KiB: two for W, as before, and THREE for A.  At the barrier in the middle of stage s a wave queues the W
+// fetch of stage s + 2 and the A fetch of stage s + 3 (W first: the next barrier's counted wait leaves the four A
+// fetches outstanding), so an A stage has two and a half stages to land.
+// The epilogue has no room of its own: it is staged in the A slot that the tile's last stage has just left, each wave
+// inside its own four DMA pieces of that slot (epilogue_rows8<.., SPLIT>), and the fetch of the next tile's stage 2, which
+// goes into the same slot, is queued by each wave when its own epilogue is through (stages 0 and 1 of the next tile
+// were fetched under the last stages, as in gemm_pipe64p_kernel).  Needs K >= 192.
+// ---------------------------------------------------------------------------
+constexpr int Q_OP = 256 * 128;        // one operand stage
+constexpr int Q_W = 3 * Q_OP;          // the W ring lies behind the three A slots
+constexpr int Q_LDS = 5 * Q_OP;        // 160 KiB
+
+// FW / FA: queue this wave's four W / four A fetches behind the barrier; waits as described above.
+template <bool SYNC, bool FW, bool FA, bool READ, int STORES = 0>
+__device__ __forceinline__ void pipe64q_substep(f32x4 (&acc)[4][8], const bf16x8 (&ca)[4], const bf16x8 (&cb)[8],
+                                                bf16x8 (&na)[4], bf16x8 (&nb)[8], const unsigned char *rd_a,
+                                                const unsigned char *rd_b, unsigned char *wr_w, unsigned char *wr_a,
+                                                const P64Src &src, int wave, bool newest_are_stores = false) {
+    if (SYNC) {
+        if (STORES > 0 && newest_are_stores)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + STORES) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (FW || FA) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const bool isa = q >= 4;
+            if (isa ? FA : FW)
+                p64_dma16(isa ? src.abase : src.wbase, isa ? src.voff_a : src.voff_b,
+                          (unsigned)(q & 3) * (isa ? src.stride_a : src.stride_b), isa ? src.max_a : src.max_b,
+                          (unsigned)(uintptr_t)LDS_PTR((isa ? wr_a : wr_w) + (wave + 8 * (q & 3)) * 1024));
+            if (READ) {   // twelve fragment reads over the eight groups: 2 1 2 1 2 1 2 1
+                const int r0 = (3 * q + 1) / 2, r1 = (3 * (q + 1) + 1) / 2;
+#pragma unroll
+                for (int r = r0; r < r1; r++) {
+                    if (r < 4) na[r] = *(const bf16x8 *)(rd_a + r * 2048);
+                    else nb[r - 4] = *(const bf16x8 *)(rd_b + (r - 4) * 2048);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int i = q >> 1, j = 4 * (q & 1) + t;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+    if (READ) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) na[i] = *(const bf16x8 *)(rd_a + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 8; j++) nb[j] = *(const bf16x8 *)(rd_b + j * 2048);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+    if (READ) {
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DS_RD, 1, 0);
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_pipe64q_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 rows x 128 columns
+    const int frow = lane & 15, fq = lane >> 4;
+    const int ntiles = g.tiles_m * g.tiles_n;
+    int vb = blockIdx.x;
+    int m0, n0;
+    auto tile_origin = [&](int b, int &mo, int &no) {
+        const int swz = xcd_remap(b, ntiles);
+        int tm, tn;
+        if (g.col_group) {
+            const int per = g.tiles_m * g.col_group;
+            const int cg = swz / per, r = swz - cg * per;
+            const int width = min(g.col_group, g.tiles_n - cg * g.col_group);
+            tm = r / width;
+            tn = cg * g.col_group + (r - tm * width);
+        } else {
+            tm = swz / g.tiles_n;
+            tn = swz - tm * g.tiles_n;
+        }
+        mo = tm * 256;
+        no = tn * 256;
+    };
+    P64Src src;
+    {
+        const int row = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        src.voff_a = (unsigned)(row * g.lda + c * 8) * 2u;
+        src.voff_b = (unsigned)(row * g.ldw + c * 8) * 2u;
+        src.chunk = (unsigned)c * 16u;
+    }
+    src.stride_a = 128u * (unsigned)g.lda;
+    src.stride_b = 128u * (unsigned)g.ldw;
+    // the lane's 16-byte chunk inside a row, recomputed where a tile's sources are set (once per tile) from the lane index
+    // passed through an opaque move: kept in a register across the stage loop it would be spilled, and its reload, a vector
+    // memory load, would wait for the fetches queued before it
+    auto lane_chunk = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int row = wave * 8 + (l >> 3);
+        return (unsigned)(((l & 7) ^ ((row >> 1) & 7)) * 16);
+    };
+    auto set_a = [&](int mo) {
+        src.abase = (const unsigned char *)(g.A + (size_t)mo * g.lda);
+        src.max_a = (unsigned)(min(g.M - 1 - mo, 255) * g.lda) * 2u + lane_chunk();
+    };
+    auto set_w = [&](int no) {
+        src.wbase = (const unsigned char *)(g.W + (size_t)no * g.ldw);
+        src.max_b = (unsigned)(min(g.N - 1 - no, 255) * g.ldw) * 2u + lane_chunk();
+    };
+    // fetch of one operand stage outside a sub-step (prologue, a tile's stage 2)
+    auto fetch_a = [&](unsigned char *slot) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            p64_dma16(src.abase, src.voff_a, (unsigned)q * src.stride_a, src.max_a, (unsigned)(uintptr_t)LDS_PTR(slot + (wave + 8 * q) * 1024));
+        src.abase += 128;
+    };
+    auto fetch_w = [&](unsigned char *slot) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            p64_dma16(src.wbase, src.voff_b, (unsigned)q * src.stride_b, src.max_b, (unsigned)(uintptr_t)LDS_PTR(slot + (wave + 8 * q) * 1024));
+        src.wbase += 128;
+    };
+    tile_origin(vb, m0, n0);
+    set_a(m0);
+    set_w(n0);
+    const int fa0 = lds_off(wm * 64 + frow, fq), fa1 = lds_off(wm * 64 + frow, 4 + fq);      // A fragments inside a slot: k 0..31, 32..63
+    const int fb0 = lds_off(wn * 128 + frow, fq), fb1 = lds_off(wn * 128 + frow, 4 + fq);
+    const int ns = g.K / 64;   // >= 3
+    fetch_w(lds + Q_W);
+    fetch_a(lds);
+    fetch_w(lds + Q_W + Q_OP);
+    fetch_a(lds + Q_OP);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int ap = 0, wp = 0;             // ring slots of the current tile's stage 0
+    bool after_full_tile = false;   // the previous tile of this workgroup issued every one of its result stores
+    f32x4 acc[4][8];
+    bf16x8 fa[2][4], fb[2][8];
+    auto next3 = [](int i) { return i == 2 ? 0 : i + 1; };
+    while (true) {
+        // this tile's stage 2 goes into the slot the previous epilogue was staged in
+        int ai = ap, wi = wp;       // slots of the stage being computed
+        fetch_a(lds + next3(next3(ap)) * Q_OP);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const unsigned char *pa = lds + ai * Q_OP, *pw = lds + Q_W + wi * Q_OP;
+#pragma unroll
+            for (int i = 0; i < 4; i++) fa[0][i] = *(const bf16x8 *)(pa + fa0 + i * 2048);
+#pragma unroll
+            for (int j = 0; j < 8; j++) fb[0][j] = *(const bf16x8 *)(pw + fb0 + j * 2048);
+        }
+        // Stages ns - 3 and ns - 2 switch the A and then the W source to the workgroup's next tile (after its last tile, to
+        // that tile's own first stages once more): scalar work inside ONE version of the stage body; with a second
+        // version the compiler no longer accumulates in place and runs out of registers.
+        const int vb_next = vb + gridDim.x;
+        const bool more = vb_next < ntiles;
+        int m1, n1;
+        tile_origin(more ? vb_next : vb, m1, n1);
+        for (int s = 0; s < ns - 1; s++) {
+            unsigned char *ca = lds + ai * Q_OP, *cw = lds + Q_W + wi * Q_OP;
+            const int an = next3(ai);
+            unsigned char *na = lds + an * Q_OP, *nw = lds + Q_W + (wi ^ 1) * Q_OP;
+            pipe64q_substep<false, false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], ca + fa1, cw + fb1, cw, ca, src, wave);
+            if (s == ns - 3) set_a(m1);
+            if (s == ns - 2) set_w(n1);
+            pipe64q_substep<true, true, true, true, epilogue_rows8_stores<EPI>()>(acc, fa[1], fb[1], fa[0], fb[0], na + fa0, nw + fb0,
+                                                                                cw, ca, src, wave, s == 0 && after_full_tile);
+            src.abase += 128;
+            src.wbase += 128;
+            ai = an;
+            wi ^= 1;
+        }
+        {   // stage ns - 1: W of the next tile's stage 1; its A slot becomes the epilogue's staging area
+            unsigned char *ca = lds + ai * Q_OP, *cw = lds + Q_W + wi * Q_OP;
+            pipe64q_substep<false, false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], ca + fa1, cw + fb1, cw, ca, src, wave);
+            pipe64q_substep<true, true, false, false>(acc, fa[1], fb[1], fa[0], fb[0], ca, cw, cw, ca, src, wave);
+            src.wbase += 128;
+            {
+                // lane index through an opaque move (see gemm_pipe64p_kernel)
+                int el = lane;
+                asm volatile("" : "+v"(el));
+                if (g.debug_mode != 6)
+                    epilogue_rows8<EPI, true>(g, acc, (float *)(ca + wave * 1024), m0 + wm * 64, n0 + wn * 128, el);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 8; j++) asm volatile("" ::"v"(acc[i][j]));
+                }
+            }
+            ai = next3(ai);
+            wi ^= 1;
+        }
+        if (!more) break;
+        after_full_tile = m0 + 256 <= g.M && n0 + 256 <= g.N && g.debug_mode != 6;
+        vb = vb_next;
+        m0 = m1;
+        n0 = n1;
+        ap = ai;
+        wp = wi;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -1584,17 +1845,28 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
             static int persist = -1;
             if (persist < 0) {
                 const char *e = getenv("SGCLIP_GEMM_PERSISTENT");
-                persist = e ? atoi(e) : 2;
+                persist = e ? atoi(e) : 1;
             }
             const int cus = device_cus();
-            // Mode 2 (default): one workgroup per tile for deep reductions with many tile columns (the ViT-L q/k/v, fc1
-            // and fc2 shapes).  Workgroups dispatched per tile run in step, so all epilogues of a round coincide and the
-            // main loops never compete with result stores for the fabric (24.5 us per tile against 26.6 us for
-            // workgroups that have drifted apart); at K >= 1024 that outweighs the 2 us of turnaround per tile.
+            // Mode 2: one workgroup per tile for deep reductions with many tile columns (the ViT-L q/k/v, fc1 and fc2
+            // shapes), where workgroups that run in step beat the two-slot persistent kernel's drifted ones by 2-3 %.
+            // With the A operand fetched two stages ahead (gemm_pipe64q_kernel) the persistent form wins there too
+            // (ViT-L fc1 2 050 -> 1 910 us, q/k/v 1 650 -> 1 605 us per 262 144 rows), so mode 1 is the default.
             const bool deep_wide = g.K >= 1024 && g.tiles_n >= 8;
             if (persist && !(persist == 2 && deep_wide) && splits == 1 && g.wide_epilogue &&
-                (g.debug_mode == 0 || g.debug_mode == 5 || g.debug_mode == 6)) {
+                (g.debug_mode == 0 || (g.debug_mode >= 5 && g.debug_mode <= 8) || g.debug_mode == 10)) {
                 const long tiles = (long)g.tiles_m * g.tiles_n;
+                static int deep_a = -1;
+                if (deep_a < 0) {
+                    const char *e = getenv("SGCLIP_GEMM_DEEP_A");
+                    deep_a = e ? atoi(e) : 1;
+                }
+                if (deep_a && g.K >= 192 && EPI != EPI_MULGRAD && g.debug_mode != 5) {
+                    lds_attr_once((const void *)gemm_pipe64q_kernel<EPI>, Q_LDS);
+                    hipLaunchKernelGGL(gemm_pipe64q_kernel<EPI>, dim3((unsigned)std::min<long>(tiles, cus)), dim3(512), Q_LDS,
+                                       stream, g);
+                    return;
+                }
                 lds_attr_once((const void *)gemm_pipe64p_kernel<EPI>, P64P_LDS);
                 hipLaunchKernelGGL(gemm_pipe64p_kernel<EPI>, dim3((unsigned)std::min<long>(tiles, cus)), dim3(512), P64P_LDS,
                                    stream, g);

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from laser_amd import _lib, ops
 dev = torch.device("cuda:0")
-M = 65536
+M = int(os.environ.get("M", 65536))
 torch.manual_seed(0)
 for name, N, K, epi in [("qkv", 2304, 768, _lib.EPI_BIAS_BF16), ("oproj", 768, 768, _lib.EPI_BIAS_RESID_F32),
                         ("fc1", 3072, 768, _lib.EPI_BIAS_GELU_BF16), ("fc2", 768, 3072, _lib.EPI_BIAS_RESID_F32)]:
