@@ -1044,17 +1044,6 @@ struct P64Src {
     unsigned stride_a, stride_b;          // uniform: 64 rows in bytes
 };
 
-// 16 bytes per lane from base + min(voff + step, limit) to LDS at lds_addr + 16 * lane.  The offset arithmetic sits inside
-// the assembly so that it is redone at every fetch in one transient register: left to the compiler the eight offsets of a
-// stage are hoisted out of the stage loop into eight registers, which then spill around the tile switch.
-__device__ __forceinline__ void p64_dma16(const unsigned char *base, unsigned voff, unsigned step, unsigned limit,
-                                          unsigned lds_addr) {
-    unsigned off;
-    asm volatile("s_mov_b32 m0, %5\n\tv_add_u32 %0, %2, %1\n\tv_min_u32 %0, %0, %3\n\tglobal_load_lds_dwordx4 %0, %4"
-                 : "=&v"(off)
-                 : "v"(voff), "s"(step), "v"(limit), "s"(base), "s"(lds_addr));
-}
-
 __device__ __forceinline__ void pipe64p_fetch(const P64Src &t, unsigned char *wr_slot, int wave) {
 #pragma unroll
     for (int q = 0; q < 8; q++) {

@@ -90,94 +90,12 @@ __device__ __forceinline__ void qa_substep(f32x4 (&acc)[4][6], const bf16x8 (&ca
     }
 }
 
-__global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs g) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 rows x 96 columns
-    const int swz = xcd_remap(blockIdx.x, gridDim.x);
-    // An XCD works through a contiguous run of the (row tile, head) sequence.  Head fastest, the 32 workgroups an XCD runs at
-    // a time cover every head of 2-3 row tiles: the x tiles are fetched once, but the whole fused weight (3 d^2 bf16,
-    // 3.5 MB at d = 768) streams through the 4 MiB L2 beside them and is fetched again for every row tile.  With the heads
-    // in groups the run walks down the row tiles inside one group: the group's weight rows stay in the L2 and each x
-    // tile is fetched once per group.
-    int tm, head;
-    if (g.head_group > 0 && g.head_group < g.heads) {
-        const int tiles_m = gridDim.x / g.heads;
-        const int per = tiles_m * g.head_group;
-        const int grp = swz / per, r = swz - grp * per;
-        const int width = min(g.head_group, g.heads - grp * g.head_group);
-        tm = r / width;
-        head = grp * g.head_group + (r - tm * width);
-    } else {
-        tm = swz / g.heads;
-        head = swz - tm * g.heads;
-    }
-    const int seq0 = tm * g.ipt;
-    const int m0 = seq0 * g.T;
+// Phases 2 and 3 (see the file header): the accumulators of the head's q, k, v tile go to LDS as three bf16 images over
+// the dead operand ring, then the waves run the attention of the tile's sequences for this head.
+__device__ __forceinline__ void qkv_attention_phases(const QkvAttnArgs &g, f32x4 (&acc)[4][6], unsigned char *lds, int wave,
+                                                     int lane, int wm, int wn, int head, int seq0, int m0) {
     const int frow = lane & 15, fq = lane >> 4;
     const int d = g.d;
-
-    f32x4 acc[4][6];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 6; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 fa[2][4], fb[2][6];
-
-    // this wave's seven pieces of a stage: q < 4: A pieces wave + 8 q (32 of them); q >= 4: W pieces wave + 8 (q - 4) (24)
-    const bf16_t *gsrc[7];
-#pragma unroll
-    for (int q = 0; q < 7; q++) {
-        const bool isw = q >= 4;
-        const int piece = wave + 8 * (isw ? q - 4 : q);
-        const int row = piece * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        if (isw) {
-            const int wrow = (row >> 6) * d + head * 64 + (row & 63);   // q, k or v block of this head
-            gsrc[q] = g.W + (size_t)wrow * g.ldw + c * 8;
-        } else {
-            int grow = m0 + row;
-            grow = grow < g.M ? grow : g.M - 1;
-            gsrc[q] = g.A + (size_t)grow * g.lda + c * 8;
-        }
-    }
-    const int a0 = lds_off(wm * 64 + frow, fq), b0 = QA_A + lds_off(wn * 96 + frow, fq);
-    const int a1 = lds_off(wm * 64 + frow, 4 + fq), b1 = QA_A + lds_off(wn * 96 + frow, 4 + fq);
-
-    const int ns = d / 64;
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int q = 0; q < 7; q++)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc[q] + t * 64), LDS_PTR(lds + t * QA_SLOT + (wave + 8 * q) * 1024), 16,
-                                             0, 0);
-#pragma unroll
-    for (int q = 0; q < 7; q++) gsrc[q] += 128;
-    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; i++) fa[0][i] = *(const bf16x8 *)(lds + a0 + i * 2048);
-#pragma unroll
-    for (int j = 0; j < 6; j++) fb[0][j] = *(const bf16x8 *)(lds + b0 + j * 2048);
-
-    int s = 0;
-    for (; s < ns - 2; s++) {
-        unsigned char *cur = lds + (s & 1) * QA_SLOT, *nxt = lds + ((s + 1) & 1) * QA_SLOT;
-        qa_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, gsrc, wave);
-        qa_substep<true, true, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0, cur, gsrc, wave);
-#pragma unroll
-        for (int q = 0; q < 7; q++) gsrc[q] += 64;
-    }
-    {
-        unsigned char *cur = lds + (s & 1) * QA_SLOT, *nxt = lds + ((s + 1) & 1) * QA_SLOT;
-        qa_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, gsrc, wave);
-        qa_substep<true, false, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0, cur, gsrc, wave);
-        qa_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], nxt + a1, nxt + b1, cur, gsrc, wave);
-        qa_substep<false, false, false>(acc, fa[1], fb[1], fa[0], fb[0], nxt, nxt, cur, gsrc, wave);
-    }
-
     if (g.debug_mode == 1) {
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -286,6 +204,279 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs g) {
     }
 }
 
+__global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 rows x 96 columns
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    // An XCD works through a contiguous run of the (row tile, head) sequence.  Head fastest, the 32 workgroups an XCD runs at
+    // a time cover every head of 2-3 row tiles: the x tiles are fetched once, but the whole fused weight (3 d^2 bf16,
+    // 3.5 MB at d = 768) streams through the 4 MiB L2 beside them and is fetched again for every row tile.  With the heads
+    // in groups the run walks down the row tiles inside one group: the group's weight rows stay in the L2 and each x
+    // tile is fetched once per group.
+    int tm, head;
+    if (g.head_group > 0 && g.head_group < g.heads) {
+        const int tiles_m = gridDim.x / g.heads;
+        const int per = tiles_m * g.head_group;
+        const int grp = swz / per, r = swz - grp * per;
+        const int width = min(g.head_group, g.heads - grp * g.head_group);
+        tm = r / width;
+        head = grp * g.head_group + (r - tm * width);
+    } else {
+        tm = swz / g.heads;
+        head = swz - tm * g.heads;
+    }
+    const int seq0 = tm * g.ipt;
+    const int m0 = seq0 * g.T;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int d = g.d;
+
+    f32x4 acc[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[2][4], fb[2][6];
+
+    // this wave's seven pieces of a stage: q < 4: A pieces wave + 8 q (32 of them); q >= 4: W pieces wave + 8 (q - 4) (24)
+    const bf16_t *gsrc[7];
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+        const bool isw = q >= 4;
+        const int piece = wave + 8 * (isw ? q - 4 : q);
+        const int row = piece * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        if (isw) {
+            const int wrow = (row >> 6) * d + head * 64 + (row & 63);   // q, k or v block of this head
+            gsrc[q] = g.W + (size_t)wrow * g.ldw + c * 8;
+        } else {
+            int grow = m0 + row;
+            grow = grow < g.M ? grow : g.M - 1;
+            gsrc[q] = g.A + (size_t)grow * g.lda + c * 8;
+        }
+    }
+    const int a0 = lds_off(wm * 64 + frow, fq), b0 = QA_A + lds_off(wn * 96 + frow, fq);
+    const int a1 = lds_off(wm * 64 + frow, 4 + fq), b1 = QA_A + lds_off(wn * 96 + frow, 4 + fq);
+
+    const int ns = d / 64;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int q = 0; q < 7; q++)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc[q] + t * 64), LDS_PTR(lds + t * QA_SLOT + (wave + 8 * q) * 1024), 16,
+                                             0, 0);
+#pragma unroll
+    for (int q = 0; q < 7; q++) gsrc[q] += 128;
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; i++) fa[0][i] = *(const bf16x8 *)(lds + a0 + i * 2048);
+#pragma unroll
+    for (int j = 0; j < 6; j++) fb[0][j] = *(const bf16x8 *)(lds + b0 + j * 2048);
+
+    int s = 0;
+    for (; s < ns - 2; s++) {
+        unsigned char *cur = lds + (s & 1) * QA_SLOT, *nxt = lds + ((s + 1) & 1) * QA_SLOT;
+        qa_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, gsrc, wave);
+        qa_substep<true, true, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0, cur, gsrc, wave);
+#pragma unroll
+        for (int q = 0; q < 7; q++) gsrc[q] += 64;
+    }
+    {
+        unsigned char *cur = lds + (s & 1) * QA_SLOT, *nxt = lds + ((s + 1) & 1) * QA_SLOT;
+        qa_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], cur + a1, cur + b1, cur, gsrc, wave);
+        qa_substep<true, false, true>(acc, fa[1], fb[1], fa[0], fb[0], nxt + a0, nxt + b0, cur, gsrc, wave);
+        qa_substep<false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], nxt + a1, nxt + b1, cur, gsrc, wave);
+        qa_substep<false, false, false>(acc, fa[1], fb[1], fa[0], fb[0], nxt, nxt, cur, gsrc, wave);
+    }
+
+    qkv_attention_phases(g, acc, lds, wave, lane, wm, wn, head, seq0, m0);
+}
+
+// ---------------------------------------------------------------------------
+// The same kernel with THREE slots for the activation operand (ns >= 4 stages).  The weights of a head are hot in the
+// XCD's L2; the activation rows stream from HBM, and fetched one stage ahead the slowest of a stage's cache lines is
+// still on its way when the workgroup reaches the stage barrier (the tower GEMMs run 11-19 % faster when their A rows
+// are L2 hits).  LDS: A ring 3 x 32 KiB, W ring 2 x 24 KiB; at the barrier in stage s a wave queues the W fetch of stage
+// s + 2, then the A fetch of stage s + 3, and the next barrier's counted wait leaves those four A fetches outstanding.
+// Fetch sources are a scalar base plus one 32-bit lane offset per operand (p64_dma16).
+// ---------------------------------------------------------------------------
+constexpr int QD_A = 256 * 128, QD_WS = 192 * 128;     // stage bytes of A and of W
+constexpr int QD_W = 3 * QD_A;                         // the W ring lies behind the three A slots
+constexpr int QD_LDS = 3 * QD_A + 2 * QD_WS;           // 144 KiB
+
+struct QdSrc {
+    const unsigned char *abase, *wbase;   // uniform, advanced by 128 bytes per stage
+    unsigned voff_a, voff_w, max_a;
+    unsigned stride_a, stride_w;          // uniform: 64 A rows / one of the q, k, v blocks of W, in bytes
+};
+
+// NW: fetches the barrier's wait leaves outstanding.  FW / FA: queue this wave's three W / four A fetches behind the barrier.
+template <bool SYNC, int NW, bool FW, bool FA, bool READ>
+__device__ __forceinline__ void qd_substep(f32x4 (&acc)[4][6], const bf16x8 (&ca)[4], const bf16x8 (&cb)[6], bf16x8 (&na)[4],
+                                           bf16x8 (&nb)[6], const unsigned char *rd_a, const unsigned char *rd_b,
+                                           unsigned char *wr_w, unsigned char *wr_a, const QdSrc &src, int wave) {
+    if (SYNC) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NW) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (FW || FA) {
+        // eight groups of three MFMAs; the first seven open with one fetch (W, W, W, A, A, A, A), the ten fragment reads
+        // are spread 2 1 1 1 2 1 1 1; fenced so that the compiler keeps the interleaving
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (q < 3 && FW)
+                p64_dma16(src.wbase, src.voff_w, (unsigned)q * src.stride_w, 0xffffffffu,
+                          (unsigned)(uintptr_t)LDS_PTR(wr_w + (wave + 8 * q) * 1024));
+            if (q >= 3 && q < 7 && FA)
+                p64_dma16(src.abase, src.voff_a, (unsigned)(q - 3) * src.stride_a, src.max_a,
+                          (unsigned)(uintptr_t)LDS_PTR(wr_a + (wave + 8 * (q - 3)) * 1024));
+            if (READ) {
+                const int r0 = q + (q > 0) + (q > 4), r1 = q + 1 + (q + 1 > 0) + (q + 1 > 4);
+#pragma unroll
+                for (int r = r0; r < r1 && r < 10; r++) {
+                    if (r < 4) na[r] = *(const bf16x8 *)(rd_a + r * 2048);
+                    else nb[r - 4] = *(const bf16x8 *)(rd_b + (r - 4) * 2048);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int m = 3 * q + t, i = m / 6, j = m - 6 * i;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
+    if (READ) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) na[i] = *(const bf16x8 *)(rd_a + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 6; j++) nb[j] = *(const bf16x8 *)(rd_b + j * 2048);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cb[j], ca[i], acc[i][j], 0, 0, 0);
+    if (READ) {
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(SG_DS_RD, 1, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void qkv_attn_deep_kernel(QkvAttnArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves of 64 rows x 96 columns
+    const int swz = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, head;   // workgroup order: see qkv_attn_kernel
+    if (g.head_group > 0 && g.head_group < g.heads) {
+        const int tiles_m = gridDim.x / g.heads;
+        const int per = tiles_m * g.head_group;
+        const int grp = swz / per, r = swz - grp * per;
+        const int width = min(g.head_group, g.heads - grp * g.head_group);
+        tm = r / width;
+        head = grp * g.head_group + (r - tm * width);
+    } else {
+        tm = swz / g.heads;
+        head = swz - tm * g.heads;
+    }
+    const int seq0 = tm * g.ipt;
+    const int m0 = seq0 * g.T;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int d = g.d;
+
+    f32x4 acc[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[2][4], fb[2][6];
+
+    // piece wave + 8 q holds tile rows 8 (wave + 8 q) .. + 7: A rows m0 + ..; W rows: block q (q, k or v) of this head, rows
+    // 8 wave .. + 7 of the block.  The chunk swizzle depends on the piece's parity, the same for every q.
+    QdSrc src;
+    {
+        const int row = wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        src.voff_a = (unsigned)(row * g.lda + c * 8) * 2u;
+        src.voff_w = (unsigned)(row * g.ldw + c * 8) * 2u;
+        src.max_a = (unsigned)(min(g.M - 1 - m0, 255) * g.lda) * 2u + (unsigned)c * 16u;
+    }
+    src.stride_a = 128u * (unsigned)g.lda;
+    src.stride_w = 2u * (unsigned)d * (unsigned)g.ldw;
+    src.abase = (const unsigned char *)(g.A + (size_t)m0 * g.lda);
+    src.wbase = (const unsigned char *)(g.W + (size_t)head * 64 * g.ldw);
+    auto fetch_a = [&](unsigned char *slot) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            p64_dma16(src.abase, src.voff_a, (unsigned)q * src.stride_a, src.max_a, (unsigned)(uintptr_t)LDS_PTR(slot + (wave + 8 * q) * 1024));
+        src.abase += 128;
+    };
+    auto fetch_w = [&](unsigned char *slot) {
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            p64_dma16(src.wbase, src.voff_w, (unsigned)q * src.stride_w, 0xffffffffu, (unsigned)(uintptr_t)LDS_PTR(slot + (wave + 8 * q) * 1024));
+        src.wbase += 128;
+    };
+    const int a0 = lds_off(wm * 64 + frow, fq), a1 = lds_off(wm * 64 + frow, 4 + fq);
+    const int b0 = lds_off(wn * 96 + frow, fq), b1 = lds_off(wn * 96 + frow, 4 + fq);
+    const int ns = d / 64;   // >= 4
+    fetch_w(lds + QD_W);
+    fetch_a(lds);
+    fetch_w(lds + QD_W + QD_WS);
+    fetch_a(lds + QD_A);
+    fetch_a(lds + 2 * QD_A);
+    asm volatile("s_waitcnt vmcnt(11)" ::: "memory");   // stage 0 has landed: W(1), A(1), A(2) may be on their way
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; i++) fa[0][i] = *(const bf16x8 *)(lds + a0 + i * 2048);
+#pragma unroll
+    for (int j = 0; j < 6; j++) fb[0][j] = *(const bf16x8 *)(lds + QD_W + b0 + j * 2048);
+
+    auto next3 = [](int i) { return i == 2 ? 0 : i + 1; };
+    int ai = 0, wi = 0, s = 0;
+    for (; s < ns - 3; s++) {   // fetches W(s + 2) and A(s + 3)
+        unsigned char *ca = lds + ai * QD_A, *cw = lds + QD_W + wi * QD_WS;
+        const int an = next3(ai);
+        unsigned char *na = lds + an * QD_A, *nw = lds + QD_W + (wi ^ 1) * QD_WS;
+        qd_substep<false, 0, false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], ca + a1, cw + b1, cw, ca, src, wave);
+        qd_substep<true, 4, true, true, true>(acc, fa[1], fb[1], fa[0], fb[0], na + a0, nw + b0, cw, ca, src, wave);
+        src.abase += 128;
+        src.wbase += 128;
+        ai = an;
+        wi ^= 1;
+    }
+    {   // stage ns - 3: the last W fetch, no A stage left
+        unsigned char *ca = lds + ai * QD_A, *cw = lds + QD_W + wi * QD_WS;
+        const int an = next3(ai);
+        unsigned char *na = lds + an * QD_A, *nw = lds + QD_W + (wi ^ 1) * QD_WS;
+        qd_substep<false, 0, false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], ca + a1, cw + b1, cw, ca, src, wave);
+        qd_substep<true, 4, true, false, true>(acc, fa[1], fb[1], fa[0], fb[0], na + a0, nw + b0, cw, ca, src, wave);
+        ai = an;
+        wi ^= 1;
+    }
+    {   // stages ns - 2 and ns - 1: nothing left to fetch, then nothing left to read
+        unsigned char *ca = lds + ai * QD_A, *cw = lds + QD_W + wi * QD_WS;
+        const int an = next3(ai);
+        unsigned char *na = lds + an * QD_A, *nw = lds + QD_W + (wi ^ 1) * QD_WS;
+        qd_substep<false, 0, false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], ca + a1, cw + b1, cw, ca, src, wave);
+        qd_substep<true, 0, false, false, true>(acc, fa[1], fb[1], fa[0], fb[0], na + a0, nw + b0, cw, ca, src, wave);
+        qd_substep<false, 0, false, false, true>(acc, fa[0], fb[0], fa[1], fb[1], na + a1, nw + b1, cw, ca, src, wave);
+        qd_substep<false, 0, false, false, false>(acc, fa[1], fb[1], fa[0], fb[0], na, nw, cw, ca, src, wave);
+    }
+    qkv_attention_phases(g, acc, lds, wave, lane, wm, wn, head, seq0, m0);
+}
+
 }  // namespace sgclip
 
 using namespace sgclip;
@@ -342,8 +533,18 @@ extern "C" int sgclip_qkv_attention(const void *x_dev, int ldx, const void *w_qk
         set_error("sgclip_qkv_attention: problem too large");
         return SGCLIP_EINVAL;
     }
-    if (!lds_attr((const void *)qkv_attn_kernel, 2 * QA_SLOT)) return SGCLIP_ELAUNCH;
+    static int deep = -1;
+    if (deep < 0) {
+        const char *e = getenv("SGCLIP_QKV_DEEP_A");
+        deep = e ? atoi(e) : 1;
+    }
     KernelTimer timer(TK_GEMM0 + SGCLIP_EPI_BIAS_BF16, 2.0 * g.M * 3.0 * d * d + 4.0 * n_seq * heads * (double)T * T * 64, stream);
+    if (deep && d >= 256 && (size_t)3 * d * ldw * 2 < (1ull << 32) && (size_t)256 * ldx * 2 < (1ull << 32)) {
+        if (!lds_attr((const void *)qkv_attn_deep_kernel, QD_LDS)) return SGCLIP_ELAUNCH;
+        hipLaunchKernelGGL(qkv_attn_deep_kernel, dim3((unsigned)grid), dim3(512), QD_LDS, stream, g);
+        return launch_check("sgclip_qkv_attention");
+    }
+    if (!lds_attr((const void *)qkv_attn_kernel, 2 * QA_SLOT)) return SGCLIP_ELAUNCH;
     hipLaunchKernelGGL(qkv_attn_kernel, dim3((unsigned)grid), dim3(512), 2 * QA_SLOT, stream, g);
     return launch_check("sgclip_qkv_attention");
 }

@@ -20,6 +20,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// LDS-DMA of 16 bytes per lane from base + min(voff + step, limit) to LDS at lds_addr + 16 * lane: `base` is uniform
+// (SGPR pair), the lane offsets are 32 bits.  The offset arithmetic sits inside the assembly so that it is redone at every
+// fetch in one transient register: left to the compiler the offsets of a stage's fetches are hoisted out of the stage
+// loop into as many registers, which then spill (and a reload, a vector memory load, waits for the fetches before it).
+__device__ __forceinline__ void p64_dma16(const unsigned char *base, unsigned voff, unsigned step, unsigned limit,
+                                          unsigned lds_addr) {
+    unsigned off;
+    asm volatile("s_mov_b32 m0, %5\n\tv_add_u32 %0, %2, %1\n\tv_min_u32 %0, %0, %3\n\tglobal_load_lds_dwordx4 %0, %4"
+                 : "=&v"(off)
+                 : "v"(voff), "s"(step), "v"(limit), "s"(base), "s"(lds_addr));
+}
+
 constexpr float NEG_BIG = -1.0e30f;
 // The running maximum of the online softmax is only a reference point: any value works as long as the exponentials stay
 // in range.  It moves only when a block's maximum exceeds it by more than this many binary orders of magnitude, so the
