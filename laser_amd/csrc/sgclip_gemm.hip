@@ -1322,10 +1322,12 @@ __device__ __forceinline__ void pipe64q_substep(f32x4 (&acc)[4][8], const bf16x8
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const bool isa = q >= 4;
-            if (isa ? FA : FW)
-                p64_dma16(isa ? src.abase : src.wbase, isa ? src.voff_a : src.voff_b,
-                          (unsigned)(q & 3) * (isa ? src.stride_a : src.stride_b), isa ? src.max_a : src.max_b,
-                          (unsigned)(uintptr_t)LDS_PTR((isa ? wr_a : wr_w) + (wave + 8 * (q & 3)) * 1024));
+            if (isa && FA)
+                p64_dma16<A_STREAMS_NT>(src.abase, src.voff_a, (unsigned)(q & 3) * src.stride_a, src.max_a,
+                                        (unsigned)(uintptr_t)LDS_PTR(wr_a + (wave + 8 * (q & 3)) * 1024));
+            if (!isa && FW)
+                p64_dma16(src.wbase, src.voff_b, (unsigned)(q & 3) * src.stride_b, src.max_b,
+                          (unsigned)(uintptr_t)LDS_PTR(wr_w + (wave + 8 * (q & 3)) * 1024));
             if (READ) {   // twelve fragment reads over the eight groups: 2 1 2 1 2 1 2 1
                 const int r0 = (3 * q + 1) / 2, r1 = (3 * (q + 1) + 1) / 2;
 #pragma unroll
@@ -1419,7 +1421,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64q_kernel(GemmArgs g) {
     auto fetch_a = [&](unsigned char *slot) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            p64_dma16(src.abase, src.voff_a, (unsigned)q * src.stride_a, src.max_a, (unsigned)(uintptr_t)LDS_PTR(slot + (wave + 8 * q) * 1024));
+            p64_dma16<A_STREAMS_NT>(src.abase, src.voff_a, (unsigned)q * src.stride_a, src.max_a, (unsigned)(uintptr_t)LDS_PTR(slot + (wave + 8 * q) * 1024));
         src.abase += 128;
     };
     auto fetch_w = [&](unsigned char *slot) {

@@ -333,7 +333,7 @@ __device__ __forceinline__ void qd_substep(f32x4 (&acc)[4][6], const bf16x8 (&ca
                 p64_dma16(src.wbase, src.voff_w, (unsigned)q * src.stride_w, 0xffffffffu,
                           (unsigned)(uintptr_t)LDS_PTR(wr_w + (wave + 8 * q) * 1024));
             if (q >= 3 && q < 7 && FA)
-                p64_dma16(src.abase, src.voff_a, (unsigned)(q - 3) * src.stride_a, src.max_a,
+                p64_dma16<A_STREAMS_NT>(src.abase, src.voff_a, (unsigned)(q - 3) * src.stride_a, src.max_a,
                           (unsigned)(uintptr_t)LDS_PTR(wr_a + (wave + 8 * (q - 3)) * 1024));
             if (READ) {
                 const int r0 = q + (q > 0) + (q > 4), r1 = q + 1 + (q + 1 > 0) + (q + 1 > 4);
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_deep_kernel(QkvAttnArgs g) {
     auto fetch_a = [&](unsigned char *slot) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            p64_dma16(src.abase, src.voff_a, (unsigned)q * src.stride_a, src.max_a, (unsigned)(uintptr_t)LDS_PTR(slot + (wave + 8 * q) * 1024));
+            p64_dma16<A_STREAMS_NT>(src.abase, src.voff_a, (unsigned)q * src.stride_a, src.max_a, (unsigned)(uintptr_t)LDS_PTR(slot + (wave + 8 * q) * 1024));
         src.abase += 128;
     };
     auto fetch_w = [&](unsigned char *slot) {
@@ -523,9 +523,19 @@ extern "C" int sgclip_qkv_attention(const void *x_dev, int ldx, const void *w_qk
         static int hg = -1;
         if (hg < 0) {
             const char *e = getenv("SGCLIP_QKV_HEAD_GROUP");
-            hg = e ? atoi(e) : 0;
+            hg = e ? atoi(e) : -2;
         }
-        g.head_group = hg;
+        if (hg >= 0) {
+            g.head_group = hg;
+        } else {
+            // Heads per group such that a group's q, k, v weight rows (3 x 64 x d bf16 per head) stay in an XCD's 4 MiB L2
+            // beside the streams (2 MB allowed), in groups of equal width.  ViT-B: two groups of 6 (x is fetched twice, the
+            // weights once: 27.7 GB per headline step at the L2's fabric side against 41.2 GB with all 12 heads side by
+            // side, where every round of 32 workgroups re-fetches the 3.5 MB weight; the launch takes the same time either way).
+            const int fit = (int)(2.0e6 / (3.0 * 64 * d * 2));
+            const int groups = fit >= heads ? 1 : ceil_div(heads, fit < 1 ? 1 : fit);
+            g.head_group = groups == 1 ? 0 : ceil_div(heads, groups);
+        }
     }
     const long long tiles_m = ceil_div(n_seq, g.ipt);
     const long long grid = tiles_m * heads;

@@ -24,13 +24,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // (SGPR pair), the lane offsets are 32 bits.  The offset arithmetic sits inside the assembly so that it is redone at every
 // fetch in one transient register: left to the compiler the offsets of a stage's fetches are hoisted out of the stage
 // loop into as many registers, which then spill (and a reload, a vector memory load, waits for the fetches before it).
+// NT: the fetch carries the non-temporal hint.  Measured on the activation stream of the tower GEMMs and the fused q/k/v
+// kernel (-DSGCLIP_A_NT=1): 3 % slower per headline step (the workgroups that share a row tile lose their L2 hits), so
+// it is off; non-temporal loads / stores of the fp32 residual in the epilogue change nothing either way.
+template <bool NT = false>
 __device__ __forceinline__ void p64_dma16(const unsigned char *base, unsigned voff, unsigned step, unsigned limit,
                                           unsigned lds_addr) {
     unsigned off;
-    asm volatile("s_mov_b32 m0, %5\n\tv_add_u32 %0, %2, %1\n\tv_min_u32 %0, %0, %3\n\tglobal_load_lds_dwordx4 %0, %4"
-                 : "=&v"(off)
-                 : "v"(voff), "s"(step), "v"(limit), "s"(base), "s"(lds_addr));
+    if constexpr (NT)
+        asm volatile("s_mov_b32 m0, %5\n\tv_add_u32 %0, %2, %1\n\tv_min_u32 %0, %0, %3\n\tglobal_load_lds_dwordx4 %0, %4 nt"
+                     : "=&v"(off)
+                     : "v"(voff), "s"(step), "v"(limit), "s"(base), "s"(lds_addr));
+    else
+        asm volatile("s_mov_b32 m0, %5\n\tv_add_u32 %0, %2, %1\n\tv_min_u32 %0, %0, %3\n\tglobal_load_lds_dwordx4 %0, %4"
+                     : "=&v"(off)
+                     : "v"(voff), "s"(step), "v"(limit), "s"(base), "s"(lds_addr));
 }
+
+#ifndef SGCLIP_A_NT
+#define SGCLIP_A_NT 0
+#endif
+constexpr bool A_STREAMS_NT = SGCLIP_A_NT != 0;
 
 constexpr float NEG_BIG = -1.0e30f;
 // The running maximum of the online softmax is only a reference point: any value works as long as the exponentials stay
