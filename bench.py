@@ -354,6 +354,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if world > 1:
+        # N ranks share the node's host cores: an even share each, at most 16 (os.cpu_count() shows the whole machine,
+        # and N x the default thread pools oversubscribe it)
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // max(world, 8))))
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist

@@ -214,6 +214,27 @@ class PredicateModel(nn.Module):
             self.invalidate_packed_weights()
         return self._flat
 
+    def gradient_reducer(self, group=None, max_bucket_bytes: int = 256 << 20, wire_dtype=None) -> "training.GradientReducer":
+        """`training.GradientReducer` over this model's flat gradient buffer with one bucket per tower (vision;
+        text + logit scale) in the buffer's layout order, plus one for any parameter outside the towers: each bucket's
+        all-reduce starts when that tower's backward is done.  Replaces the reference's DDP wrapper
+        (scripts/train_sgclip.py:203-213)."""
+        flat = self.flatten_parameters()
+        tt = self._trainers()
+        buckets, off = [], 0
+        for prefix in TOWER_PREFIXES:
+            vision, text = tt[prefix][:2]
+            v_end = flat.index[f"{prefix}.{text.names[0]}"][0]
+            ls = flat.index[f"{prefix}.logit_scale"]
+            t_end = ls[0] + (ls[1] + flat.ALIGN - 1) // flat.ALIGN * flat.ALIGN
+            buckets += [(f"{prefix}.vision", off, v_end), (f"{prefix}.text", v_end, t_end)]
+            vision.bucket_key, text.bucket_key = f"{prefix}.vision", f"{prefix}.text"
+            off = t_end
+        if off < flat.total:
+            buckets.append(("rest", off, flat.total))
+        return training.GradientReducer(flat, buckets, group, max_bucket_bytes, wire_dtype,
+                                        towers=[t for prefix in TOWER_PREFIXES for t in tt[prefix][:2]])
+
     def set_recompute_chunk(self, images: Optional[int], keep_activations: bool = True):
         """Bound the activation memory of the train step: the image towers run `images` crops at a time and recompute
         a chunk's forward during backward (None: one pass, keep everything).  With keep_activations, chunks keep

@@ -68,6 +68,9 @@ class TrainTower:
         self._w: Dict[str, torch.Tensor] = {}
         self._zero_bias = torch.zeros(max(3 * self.d, self.ffn), dtype=F32, device=self.device)
         self.flat: Optional["FlatParameters"] = None   # set by FlatParameters.attach
+        self.reducer: Optional["GradientReducer"] = None   # set by GradientReducer: told when this tower's backward is done
+        self.bucket_key: Optional[str] = None
+        self.backward_pending = 0                      # forward passes of this step whose backward has not run yet
         self.flat_prefix = ""
         self.recompute_chunk: Optional[int] = None      # images per recomputed chunk (None: keep all activations)
         self.keep_activations = True    # chunked: keep the activations of as many chunks as free memory allows
@@ -356,6 +359,7 @@ class _TowerFn(torch.autograd.Function):
         feature calls in torch.utils.checkpoint the same way, llava_clip_model_v3.py:52-83)."""
         ctx.tower, ctx.run, ctx.chunks = tower, run, chunks
         ctx.kept = {}
+        tower.backward_pending += 1
         if len(chunks) == 1:
             tower.save_extras = bool(tower.recompute_chunk)
             feats, ctx.saved = run(*chunks[0])
@@ -390,6 +394,9 @@ class _TowerFn(torch.autograd.Function):
                     _, saved = ctx.run(lo, hi)
                 ctx.tower.backward(saved, dfeat[lo:hi], sink)
                 del saved
+        ctx.tower.backward_pending -= 1
+        if ctx.tower.reducer is not None and ctx.tower.backward_pending <= 0:
+            ctx.tower.reducer.ready(ctx.tower.bucket_key)     # every gradient of this tower lies in the flat buffer
         return (None, None, None) + tuple(sink.autograd_outputs())
 
 
@@ -569,3 +576,108 @@ def allreduce_gradients(params, group=None, bucket_bytes: int = 256 << 20):
         if size >= bucket_bytes:
             flush()
     flush()
+
+
+class GradientReducer:
+    """Gradient averaging over the ranks that overlaps with backward: the flat gradient buffer is cut into one bucket per
+    tower, and a bucket's all-reduce is queued as soon as that tower's backward has finished, while the towers that
+    come later in backward are still computing.  The reference gets the same effect from DistributedDataParallel's
+    bucketed reducer (scripts/train_sgclip.py:203-213 wraps the model in DDP); here the buckets follow the towers
+    because a tower's backward is one node of the autograd graph, and they are views of the flat buffer, so nothing is
+    packed or copied.
+
+    Every rank issues the same collectives in the same order whatever its batch looks like: buckets are launched in
+    the fixed sequence `order`, a bucket goes out when it is ready AND all buckets before it have gone out, and
+    `finish()` launches whatever is left (a tower this rank's batch never used contributes zeros).  `order` starts as
+    the reverse of the buffer layout; after the first step rank 0's observed completion order is broadcast and used
+    from then on, so that buckets leave in the order backward really finishes them.
+
+    On GPUs (backend nccl = RCCL) the collectives run asynchronously on the process group's own stream, ordered after
+    the kernels queued so far on the calling stream; `finish()` makes the calling stream wait for them.  With
+    `wire_dtype=torch.bfloat16` a bucket is averaged in bf16 (half the bytes over xGMI, about three significant digits
+    per gradient element) and written back to the fp32 buffer.
+
+        reducer = model.gradient_reducer()
+        for batch in loader:
+            opt.zero_grad(); reducer.begin()
+            loss(model(**batch)).backward()
+            reducer.finish(); opt.step()
+    """
+
+    def __init__(self, flat: FlatParameters, buckets, group=None, max_bucket_bytes: int = 256 << 20, wire_dtype=None,
+                 towers: Sequence["TrainTower"] = ()):
+        """buckets: list of (key, lo, hi) element ranges of flat.grad that together cover the buffer once.
+        towers: the TrainTowers that report to this reducer (`bucket_key` set); they call ready(key) themselves."""
+        import torch.distributed as dist
+        self.flat, self.group, self.wire_dtype = flat, group, wire_dtype
+        self.towers = list(towers)
+        for t in self.towers:
+            t.reducer = self
+        self.buckets = {k: (lo, hi) for k, lo, hi in buckets}
+        spans = sorted(self.buckets.values())
+        assert spans and spans[0][0] == 0 and spans[-1][1] == flat.total and \
+            all(a[1] == b[0] for a, b in zip(spans, spans[1:])), "buckets must tile the flat gradient buffer"
+        self.order = [k for k, _, _ in reversed(list(buckets))]
+        self.max_elems = max(1, max_bucket_bytes // 4)
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.native_avg = self.active and dist.get_backend(group) == "nccl"
+        self._order_agreed = False
+        self.launch_log: List[str] = []       # bucket keys in the order the last step launched them
+        self.begin()
+
+    def begin(self):
+        """Start of a step (before forward)."""
+        self._ready, self._launched, self._pending = set(), 0, []
+        for t in self.towers:
+            t.backward_pending = 0     # forward passes without a backward (scoring under no_grad) count for nothing
+        self._seen: List[str] = []
+        self.launch_log = []
+
+    def ready(self, key: str):
+        """The gradients of bucket `key` are final on the calling stream (called by the towers' backward)."""
+        if key not in self.buckets or key in self._ready:
+            return
+        self._ready.add(key)
+        self._seen.append(key)
+        self._launch_ready()
+
+    def _launch_ready(self):
+        while self._launched < len(self.order) and self.order[self._launched] in self._ready:
+            self._launch(self.order[self._launched])
+            self._launched += 1
+
+    def _launch(self, key: str):
+        import torch.distributed as dist
+        self.launch_log.append(key)
+        if not self.active:
+            return
+        lo, hi = self.buckets[key]
+        op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
+        for a in range(lo, hi, self.max_elems):
+            piece = self.flat.grad[a: min(hi, a + self.max_elems)]
+            wire = piece.to(self.wire_dtype) if self.wire_dtype is not None and self.wire_dtype != piece.dtype else piece
+            work = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
+            self._pending.append((work, piece, wire))
+
+    def finish(self):
+        """After backward: launch what is left, wait for every bucket, leave the averages in flat.grad."""
+        import torch.distributed as dist
+        for key in self.order[self._launched:]:
+            self._launch(key)
+        self._launched = len(self.order)
+        for work, piece, wire in self._pending:
+            work.wait()               # nccl: the calling stream waits; gloo: the host does
+            if wire is not piece:
+                piece.copy_(wire)
+            if not self.native_avg:
+                piece.div_(self.world)
+        self._pending = []
+        if self.active and not self._order_agreed:
+            # rank 0's completion order of this first step (buckets its batch never touched go last, as laid out)
+            seen = self._seen + [k for k in self.order if k not in self._seen]
+            box = [seen]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                       group=self.group)
+            self.order = list(box[0])
+            self._order_agreed = True

@@ -4,6 +4,7 @@ import os
 import socket
 import zlib
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -222,3 +223,89 @@ def test_allreduce_gradients_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+class _StubTower:
+    """What GradientReducer needs from a tower: a bucket key and the pending-backward count it resets."""
+
+    def __init__(self, key):
+        self.bucket_key, self.reducer, self.backward_pending = key, None, 0
+
+
+def _reducer_worker(rank, world, port, q):
+    from laser_amd.training import FlatParameters, GradientReducer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes = {"a.vision": 301, "a.text": 64, "b.vision": 1000, "b.text": 7}
+        named = [(k, torch.nn.Parameter(torch.zeros(n))) for k, n in sizes.items()]
+        flat = FlatParameters(named)
+        buckets, off = [], 0
+        for k, _ in named:
+            lo, cnt, _ = flat.index[k]
+            end = lo + (cnt + flat.ALIGN - 1) // flat.ALIGN * flat.ALIGN
+            buckets.append((k, lo, end))
+            off = end
+        assert off == flat.total
+        towers = [_StubTower(k) for k in sizes]
+        ok, logs = True, []
+        for wire in (None, torch.bfloat16):
+            red = GradientReducer(flat, buckets, max_bucket_bytes=1024, wire_dtype=wire, towers=towers)   # b.vision: 4 pieces
+            assert all(t.reducer is red for t in towers)
+            for step in range(3):
+                flat.zero_grad()
+                red.begin()
+                for i, (k, p) in enumerate(named):
+                    p.grad.fill_(float((rank + 1) * (i + 1) * (step + 1)))
+                # backward finishes the towers in an order of its own, different per rank; rank 1's batch never
+                # touches b.text (its gradient stays zero and the bucket leaves in finish())
+                done = ["b.vision", "a.text", "b.text", "a.vision"] if rank == 0 else ["a.text", "a.vision", "b.vision"]
+                if rank == 1:
+                    named[3][1].grad.zero_()
+                for k in done:
+                    red.ready(k)
+                red.finish()
+                logs.append(tuple(red.launch_log))
+                for i, (k, p) in enumerate(named):
+                    want = (1 + 2) / 2 * (i + 1) * (step + 1)
+                    if k == "b.text":
+                        want = 1 * (i + 1) * (step + 1) / 2
+                    ok = ok and torch.allclose(p.grad, torch.full_like(p, want), rtol=1e-2 if wire is not None else 1e-6)
+                if step >= 1:    # rank 0's completion order of the first step, on every rank
+                    ok = ok and logs[-1] == ("b.vision", "a.text", "b.text", "a.vision")
+        gathered = [None] * world
+        dist.all_gather_object(gathered, logs)
+        ok = ok and all(g == gathered[0] for g in gathered)      # same collectives in the same order everywhere
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_reducer_bucket_per_tower_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_gradient_reducer_single_process_is_a_no_op():
+    from laser_amd.training import FlatParameters, GradientReducer
+    named = [("x", torch.nn.Parameter(torch.zeros(5))), ("y", torch.nn.Parameter(torch.zeros(8)))]
+    flat = FlatParameters(named)
+    red = GradientReducer(flat, [("x", 0, 8), ("y", 8, 16)])
+    named[0][1].grad.fill_(3.0)
+    red.begin()
+    red.ready("y")
+    assert red.launch_log == ["y"]          # layout order reversed: y leaves first
+    red.finish()
+    assert red.launch_log == ["y", "x"] and float(named[0][1].grad[0]) == 3.0
+    with pytest.raises(AssertionError):
+        GradientReducer(flat, [("x", 0, 8)])

@@ -340,3 +340,35 @@ def test_c5_train_step_at_full_size():
           f"peak memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
     del model, flat, opt
     torch.cuda.empty_cache()
+
+
+def test_gradient_reducer_is_told_by_every_tower_during_backward():
+    """One process (no collective runs): the towers report their buckets while backward is still going, every bucket
+    exactly once, the buckets tile the flat buffer, and a scoring pass between steps does not confuse the counts."""
+    b = make_clip_batch(17, n_videos=1, frames=2, objects=3, H=96, W=128, k_cate=4, k_unary=5, k_binary=3, min_box=12,
+                        max_box=90)
+    kw = b.forward_kwargs()
+    cfg, sd, tok, model = _setup(31, float(np.log(10.0)))
+    model.enable_training()
+    flat = model.flatten_parameters()
+    red = model.gradient_reducer()
+    spans = sorted(red.buckets.values())
+    assert spans[0][0] == 0 and spans[-1][1] == flat.total and all(a[1] == c[0] for a, c in zip(spans, spans[1:]))
+    assert set(red.buckets) >= {f"{p}.{k}" for p in TOWER_PREFIXES for k in ("vision", "text")}
+    for step in range(2):
+        with torch.no_grad():
+            model(**kw)                       # forward passes that never get a backward
+        flat.zero_grad()
+        red.begin()
+        loss, _ = _loss(model(**kw), 4)
+        seen_during_backward = []
+        ready = red.ready
+        red.ready = lambda key: (seen_during_backward.append(key), ready(key))[1]
+        loss.backward()
+        red.ready = ready
+        assert sorted(seen_during_backward) == sorted(k for k in red.buckets if k != "rest"), seen_during_backward
+        red.finish()
+        assert sorted(red.launch_log) == sorted(red.buckets)
+    torch.cuda.synchronize()
+    del model, flat, red
+    torch.cuda.empty_cache()
