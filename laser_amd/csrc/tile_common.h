@@ -5,6 +5,7 @@
 namespace sgclip {
 
 // sched_group_barrier instruction classes
+#define SG_VALU 0x002
 #define SG_MFMA 0x008
 #define SG_VMEM_RD 0x020
 #define SG_DS_RD 0x100

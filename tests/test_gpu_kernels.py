@@ -164,7 +164,10 @@ def _attn_ref(qkv, n_seq, T, heads, causal, key_mask):
                                                   (2, 32, 2, True), (7, 64, 3, False),
                                                   # T >= 128: the kernel that shares K / V blocks between four query tiles
                                                   (3, 128, 2, False), (2, 200, 3, True), (1, 130, 1, True), (2, 577, 16, False),
-                                                  (2, 257, 2, True)])
+                                                  (2, 257, 2, True),
+                                                  # no masks, T >= 128: query groups that end in one tile, one row, a full group
+                                                  (3, 257, 2, False), (2, 197, 3, False), (2, 129, 1, False), (1, 160, 2, False),
+                                                  (2, 192, 2, False), (1, 256, 1, False), (1, 1025, 1, False)])
 def test_attention(dev, n_seq, T, heads, causal):
     qkv = _rand_bf16((n_seq * T, 3 * heads * 64), dev, 1.0, 5)
     key_mask = None

@@ -23,6 +23,15 @@ __global__ __launch_bounds__(256) void rate_kernel(float *out, int iters, float 
                 if (OP == 3) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(v[(i + 1) & 7]), "v"(v[(i + 2) & 7]));
                 if (OP == 5) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
                 if (OP == 6) v[i] = __builtin_amdgcn_exp2f(v[i]) + v[(i + 3) & 7] * 0.25f;   // exp + fma mix
+                if (OP == 7) asm volatile("v_exp_f16 %0, %0" : "+v"(v[i]));
+                if (OP == 8) asm volatile("v_rcp_f16 %0, %0" : "+v"(v[i]));
+                if (OP == 9) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(f32x2 *)&v[i & 6]) : "v"(*(f32x2 *)&v[(i + 2) & 6]));
+                if (OP == 10) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+                if (OP == 11) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+                if (OP == 12) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+                if (OP == 13) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+                if (OP == 14) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
+                if (OP == 15) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(v[i]) : "v"(v[(i + 1) & 7]));
             }
             if (OP == 4) {
 #pragma unroll
@@ -72,5 +81,14 @@ int main() {
     run<4>("v_pk_mul_f32 (2 regs)", 32);
     run<5>("v_cvt_pk_bf16_f32", 64);
     run<6>("v_exp_f32 + v_fma_f32 pair", 64);
+    run<7>("v_exp_f16", 64);
+    run<8>("v_rcp_f16", 64);
+    run<9>("v_pk_fma_f32", 64);
+    run<10>("v_pk_add_f16", 64);
+    run<11>("v_add_f32", 64);
+    run<12>("v_max_f32", 64);
+    run<13>("v_mul_f32", 64);
+    run<14>("v_cvt_pk_f16_f32", 64);
+    run<15>("v_pk_mul_f16", 64);
     return 0;
 }
