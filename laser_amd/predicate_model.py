@@ -235,14 +235,18 @@ class PredicateModel(nn.Module):
         return training.GradientReducer(flat, buckets, group, max_bucket_bytes, wire_dtype,
                                         towers=[t for prefix in TOWER_PREFIXES for t in tt[prefix][:2]])
 
-    def set_recompute_chunk(self, images: Optional[int], keep_activations: bool = True):
+    def set_recompute_chunk(self, images: Optional[int], keep_activations: bool = True, max_kept_bytes: Optional[int] = None):
         """Bound the activation memory of the train step: the image towers run `images` crops at a time and recompute
         a chunk's forward during backward (None: one pass, keep everything).  With keep_activations, chunks keep
-        their activations while the card has memory to spare and only the rest are recomputed."""
+        their activations while the card has memory to spare and, if given, while the kept chunks of ALL towers together
+        stay within `max_kept_bytes`; only the rest are recomputed.  keep_activations=False is the bounded-memory mode:
+        peak memory is one chunk's activations plus the parameters, independent of the batch and of allocator state."""
+        budget = training.KeptBudget(max_kept_bytes)
         for prefix in TOWER_PREFIXES:
             tower = self._trainers()[prefix][0]
             tower.recompute_chunk = images
             tower.keep_activations = keep_activations
+            tower.kept_budget = budget
 
     def _grad_mode(self) -> bool:
         return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())

@@ -74,7 +74,7 @@ class TrainTower:
         self.flat_prefix = ""
         self.recompute_chunk: Optional[int] = None      # images per recomputed chunk (None: keep all activations)
         self.keep_activations = True    # chunked: keep the activations of as many chunks as free memory allows
-        self.save_extras = False        # also save what one elementwise pass rebuilds (LayerNorm outputs, activation)
+        self.kept_budget: Optional["KeptBudget"] = None   # shared by the towers of a model: bytes kept chunks may hold
 
     def param_list(self) -> List[nn.Parameter]:
         return [self.params[n] for n in self.names]
@@ -107,7 +107,7 @@ class TrainTower:
         return self.params[name].detach()
 
     # -- encoder layers -----------------------------------------------------------------------
-    def _layer_forward(self, i, x, n_seq, T, causal, km):
+    def _layer_forward(self, i, x, n_seq, T, causal, km, save_extras: bool = False):
         b, w, d = f"{self.pre}.encoder.layers.{i}", self._w, self.d
         M = x.shape[0]
         h1 = ops.layernorm(x, self._p(f"{b}.layer_norm1.weight"), self._p(f"{b}.layer_norm1.bias"), self.eps)
@@ -124,9 +124,9 @@ class TrainTower:
         ops.gemm_bf16(h2, w[f"{i}.fc1"], u, _lib.EPI_BIAS_GELU_BOTH_BF16, bias=self._p(f"{b}.mlp.fc1.bias"), aux=g)
         x_out = torch.empty_like(x)
         ops.gemm_bf16(g, w[f"{i}.fc2"], x_out, _lib.EPI_BIAS_RESID_F32, bias=self._p(f"{b}.mlp.fc2.bias"), aux=x_mid)
-        # a recomputed chunk's saved set lives for that chunk's backward only, so the cheap-to-recompute tensors
-        # (LayerNorm outputs, the activation) are kept as well; otherwise they are rebuilt in backward to save memory
-        extra = (h1, h2, g) if self.save_extras else None
+        # save_extras: also keep what one elementwise pass rebuilds (LayerNorm outputs, the activation).  A recomputed
+        # chunk's saved set lives for that chunk's backward only, so it keeps them; otherwise backward rebuilds them
+        extra = (h1, h2, g) if save_extras else None
         return x_out, (x, qkv, a, x_mid, u, extra)
 
     def _layer_backward(self, i, saved, dx, n_seq, T, causal, km, sink: "GradSink"):
@@ -167,7 +167,7 @@ class TrainTower:
                         sink.get(f"{b}.layer_norm1.bias"), dx=dx, accumulate=True)
 
     # -- whole towers -------------------------------------------------------------------------
-    def forward_images(self, patches: torch.Tensor, n: int):
+    def forward_images(self, patches: torch.Tensor, n: int, save_extras: bool = False):
         """patches: bf16 [n * P, kpad] from the crop kernel.  Returns (features f32 [n, proj], saved)."""
         assert self.vision
         self.refresh()
@@ -181,7 +181,7 @@ class TrainTower:
                           self.eps, out_dtype=_lib.DTYPE_F32)
         layers = []
         for i in range(self.L):
-            x, s = self._layer_forward(i, x, n, T, False, None)
+            x, s = self._layer_forward(i, x, n, T, False, None, save_extras)
             layers.append(s)
         rows = torch.from_numpy(np.arange(n, dtype=np.int32) * T).to(self.device)
         xp = x.index_select(0, rows.long())
@@ -190,7 +190,8 @@ class TrainTower:
         feats = self._project(pl, self._p("visual_projection.weight"))
         return feats, dict(patches=patches, emb=emb, layers=layers, rows=rows, xp=xp, pl=pl, n=n, T=T, km=None)
 
-    def forward_text(self, ids: torch.Tensor, attention_mask: Optional[torch.Tensor], rows: torch.Tensor):
+    def forward_text(self, ids: torch.Tensor, attention_mask: Optional[torch.Tensor], rows: torch.Tensor,
+                     save_extras: bool = False):
         """ids int32 [K, T] and attention_mask int32 [K, T] (or None) on the device; rows int32 [K]: k * T + position
         of the end-of-text token of row k (modeling_clip.py:561-581)."""
         assert not self.vision
@@ -200,7 +201,7 @@ class TrainTower:
                          self._p("text_model.embeddings.position_embedding.weight"), ids)
         layers = []
         for i in range(self.L):
-            x, s = self._layer_forward(i, x, K, T, True, attention_mask)
+            x, s = self._layer_forward(i, x, K, T, True, attention_mask, save_extras)
             layers.append(s)
         xp = x.index_select(0, rows.long())
         pl = ops.layernorm(xp, self._p("text_model.final_layer_norm.weight"), self._p("text_model.final_layer_norm.bias"),
@@ -354,29 +355,32 @@ class _TowerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tower: TrainTower, run, chunks, *params):
-        """run(lo, hi) -> (features, saved) for items lo..hi; chunks: list of (lo, hi).  With more than one chunk
-        backward recomputes the forward of the chunks whose activations were not kept (the reference wraps its
-        feature calls in torch.utils.checkpoint the same way, llava_clip_model_v3.py:52-83)."""
+        """run(lo, hi, save_extras) -> (features, saved) for items lo..hi; chunks: list of (lo, hi).  With more than
+        one chunk backward recomputes the forward of the chunks whose activations were not kept (the reference wraps
+        its feature calls in torch.utils.checkpoint the same way, llava_clip_model_v3.py:52-83)."""
         ctx.tower, ctx.run, ctx.chunks = tower, run, chunks
         ctx.kept = {}
         tower.backward_pending += 1
         if len(chunks) == 1:
-            tower.save_extras = bool(tower.recompute_chunk)
-            feats, ctx.saved = run(*chunks[0])
+            feats, ctx.saved = run(*chunks[0], bool(tower.recompute_chunk))
             return feats
         # Recompute costs a second forward, a quarter of the step's GEMM work, and is only worth it for the memory it
         # frees: with 288 GB on the card most batches need little of it.  Chunks keep their saved sets (without the
-        # cheap extras) while the card's free memory stays above what the backward of a recomputed chunk needs.
+        # cheap extras) while the card's free memory stays above what the backward of a recomputed chunk needs AND the
+        # model's kept-bytes budget (all towers together) has room.  keep_activations = False is the bounded-memory mode:
+        # one chunk's activations at a time, whatever the card holds.
         ctx.saved = None
-        tower.save_extras = False
         dev, feats, per = tower.device, [], 0
+        budget = tower.kept_budget
         for idx, (lo, hi) in enumerate(chunks):
             before = torch.cuda.memory_allocated(dev)
-            f, saved = run(lo, hi)
+            f, saved = run(lo, hi, False)
             feats.append(f)
-            per = max(per, torch.cuda.memory_allocated(dev) - before)
-            if tower.keep_activations and _headroom(dev) > 2.5 * per + (12 << 30):
-                ctx.kept[idx] = saved
+            held = torch.cuda.memory_allocated(dev) - before
+            per = max(per, held)
+            # 2.5 x: a recomputed chunk's backward holds its saved set with the extras (+ 50 %) and its gradients
+            if tower.keep_activations and _headroom(dev) > 2.5 * per + (12 << 30) and (budget is None or budget.take(held)):
+                ctx.kept[idx] = (saved, held)
             del saved
         return torch.cat(feats, dim=0)
 
@@ -387,24 +391,43 @@ class _TowerFn(torch.autograd.Function):
             ctx.tower.backward(ctx.saved, dfeat, sink)
             ctx.saved = None
         else:
+            budget = ctx.tower.kept_budget
             for idx, (lo, hi) in enumerate(ctx.chunks):
-                saved = ctx.kept.pop(idx, None)
+                saved, held = ctx.kept.pop(idx, (None, 0))
                 if saved is None:
-                    ctx.tower.save_extras = True
-                    _, saved = ctx.run(lo, hi)
+                    _, saved = ctx.run(lo, hi, True)
                 ctx.tower.backward(saved, dfeat[lo:hi], sink)
                 del saved
+                if budget is not None and held:
+                    budget.give_back(held)
         ctx.tower.backward_pending -= 1
         if ctx.tower.reducer is not None and ctx.tower.backward_pending <= 0:
             ctx.tower.reducer.ready(ctx.tower.bucket_key)     # every gradient of this tower lies in the flat buffer
         return (None, None, None) + tuple(sink.autograd_outputs())
 
 
+class KeptBudget:
+    """Bytes of activations that kept (not recomputed) chunks may hold, shared by every tower of a model so that what the
+    first towers keep counts when the largest one runs.  limit None: bounded by the card's free memory only."""
+
+    def __init__(self, limit: Optional[int] = None):
+        self.limit, self.used = limit, 0
+
+    def take(self, n: int) -> bool:
+        if self.limit is not None and self.used + n > self.limit:
+            return False
+        self.used += n
+        return True
+
+    def give_back(self, n: int):
+        self.used = max(0, self.used - n)
+
+
 def encode_images(tower: TrainTower, patches: torch.Tensor, n: int) -> torch.Tensor:
     P = tower.cfg.n_patches
     c = tower.recompute_chunk
     chunks = [(0, n)] if not c or n <= c else [(lo, min(n, lo + c)) for lo in range(0, n, c)]
-    return _TowerFn.apply(tower, lambda lo, hi: tower.forward_images(patches[lo * P: hi * P], hi - lo), chunks,
+    return _TowerFn.apply(tower, lambda lo, hi, extras: tower.forward_images(patches[lo * P: hi * P], hi - lo, extras), chunks,
                           *tower.param_list())
 
 
@@ -425,7 +448,8 @@ def encode_text(tower: TrainTower, input_ids: torch.Tensor, attention_mask: Opti
     if attention_mask is not None:
         am = attention_mask[:, :T].to(dev, torch.int32).contiguous()
     rows = torch.from_numpy((np.arange(len(pos)) * T + pos).astype(np.int32)).to(dev)
-    return _TowerFn.apply(tower, lambda lo, hi: tower.forward_text(ids, am, rows), [(0, ids.shape[0])], *tower.param_list())
+    return _TowerFn.apply(tower, lambda lo, hi, extras: tower.forward_text(ids, am, rows, extras), [(0, ids.shape[0])],
+                          *tower.param_list())
 
 
 class _SimilarityFn(torch.autograd.Function):

@@ -132,7 +132,7 @@ def test_flat_parameters_and_chunked_recompute_give_the_same_gradients():
                         max_box=90)
     kw = b.forward_kwargs()
     results = []
-    for mode in ("loose", "flat", "flat+recompute", "flat+chunks kept"):
+    for mode in ("loose", "flat", "flat+recompute", "flat+chunks kept", "flat+kept within a budget"):
         cfg, sd, tok, model = _setup(24, float(np.log(10.0)))
         model.enable_training()
         if mode != "loose":
@@ -142,8 +142,15 @@ def test_flat_parameters_and_chunked_recompute_give_the_same_gradients():
             model.set_recompute_chunk(5, keep_activations=False)
         if mode == "flat+chunks kept":
             model.set_recompute_chunk(5)
+        if mode == "flat+kept within a budget":      # all towers together may keep 3 MB: some chunks kept, some recomputed
+            model.set_recompute_chunk(5, max_kept_bytes=3 << 20)
         out = model(**kw)
-        if mode.startswith("flat+"):
+        if mode == "flat+kept within a budget":
+            fns = [f for f in _tower_nodes(out) if len(f.chunks) > 1]
+            kept, total = sum(len(f.kept) for f in fns), sum(len(f.chunks) for f in fns)
+            held = sum(h for f in fns for _, h in f.kept.values())
+            assert 0 < kept < total and held <= 3 << 20 and fns[0].tower.kept_budget.used == held, (kept, total, held)
+        elif mode.startswith("flat+"):
             fns = [f for f in _tower_nodes(out) if len(f.chunks) > 1]
             assert fns and all(len(f.kept) == (len(f.chunks) if mode == "flat+chunks kept" else 0) for f in fns)
         loss, _ = _loss(out, 3)
@@ -157,9 +164,9 @@ def test_flat_parameters_and_chunked_recompute_give_the_same_gradients():
             assert ((flat.grad - 2 * once).norm() / (2 * once).norm()).item() <= 1e-4     # accumulation
             flat.zero_grad()
             assert float(flat.grad.abs().max()) == 0.0
-    (l0, g0), (l1, g1), (l2, g2), (l3, g3) = results
-    assert all(abs(l0 - l) <= 1e-5 * max(1, abs(l0)) for l in (l1, l2, l3))
-    for other in (g1, g2, g3):
+    (l0, g0), (l1, g1), (l2, g2), (l3, g3), (l4, g4) = results
+    assert all(abs(l0 - l) <= 1e-5 * max(1, abs(l0)) for l in (l1, l2, l3, l4))
+    for other in (g1, g2, g3, g4):
         assert set(other) == set(g0)
         a = torch.cat([g0[k].reshape(-1) for k in sorted(g0)])
         o = torch.cat([other[k].reshape(-1) for k in sorted(g0)])
