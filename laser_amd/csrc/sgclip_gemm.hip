@@ -42,8 +42,9 @@ struct GemmArgs {
     int aux_rows;
     int tiles_m, tiles_n;
     int wide_epilogue;  // N % 8 == 0, ldc % 8 == 0 and C, bias, aux 16-byte aligned
-    int debug_mode;     // diagnostics only: 1 = skip epilogue stores, 2 = single K step, 5 = per-workgroup time trace,
-                        // 6 = no epilogue, 7 / 8 / 10 = every tile reads the first tile's operands (both / A / W)
+    int debug_mode;     // diagnostics only: 1 = skip epilogue stores, 2 = single K step, 3 / 4 = main-loop studies of
+                        // gemm_pipe64_kernel, 5 = per-workgroup time trace, 6 = no epilogue (persistent kernels),
+                        // 9 = every tile stores to the first 256 rows
     float *colsum;      // EPI_MULGRAD through epilogue_passes: += column sums of C (null: none)
     int col_group;      // gemm_pipe64_kernel: tiles walk down the rows inside groups of this many tile columns (0: row major)
     int tn_gm, tn_gn, tn_upx;   // gemm_tn_kernel: tile group shape and (group, slice) units per XCD (tn_gm = 0: plain grid)
@@ -1275,7 +1276,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe64p_kernel(GemmArgs g) {
             g_pipe64_trace[16 * vb + 2] = t;
         }
         if (!more) break;   // (the wave's end waits for the fetches still in flight)
-        after_full_tile = m0 + 256 <= g.M && n0 + 256 <= g.N && (g.debug_mode == 0 || g.debug_mode == 5 || g.debug_mode == 7 || g.debug_mode == 8 || g.debug_mode == 10) && !(EPI == EPI_MULGRAD && g.colsum);
+        after_full_tile = m0 + 256 <= g.M && n0 + 256 <= g.N && (g.debug_mode == 0 || g.debug_mode == 5) && !(EPI == EPI_MULGRAD && g.colsum);
         vb = vb_next;
         m0 = m1;
         n0 = n1;
@@ -1845,7 +1846,7 @@ static void launch(const GemmArgs &g0, hipStream_t stream, int splits = 1) {
             // (ViT-L fc1 2 050 -> 1 910 us, q/k/v 1 650 -> 1 605 us per 262 144 rows), so mode 1 is the default.
             const bool deep_wide = g.K >= 1024 && g.tiles_n >= 8;
             if (persist && !(persist == 2 && deep_wide) && splits == 1 && g.wide_epilogue &&
-                (g.debug_mode == 0 || (g.debug_mode >= 5 && g.debug_mode <= 8) || g.debug_mode == 10)) {
+                (g.debug_mode == 0 || g.debug_mode == 5 || g.debug_mode == 6)) {
                 const long tiles = (long)g.tiles_m * g.tiles_n;
                 static int deep_a = -1;
                 if (deep_a < 0) {
