@@ -62,6 +62,15 @@ class PendingInputs:
     def result(self):
         return self._future.result()
 
+    def discard(self):
+        """Give the staged clip up without scoring it: its buffer set becomes reusable.  (A clip that is staged and then
+        neither passed to forward() nor discarded keeps its buffer set, and the submission that needs the set next
+        waits for it.)"""
+        di = self._future.result()
+        if di.slot is not None:
+            di.slot.release()
+            di.slot = None
+
 
 def _frame_layout(batched_videos):
     frame_off, frame_hw, arrs, off = [], [], [], 0
@@ -116,6 +125,7 @@ class InputStager:
         self._worker = ThreadPoolExecutor(1, thread_name_prefix="sgclip-stage")       # clips are staged in submission order
         self._packers = ThreadPoolExecutor(max(1, pack_threads), thread_name_prefix="sgclip-pack")
         self._pack_threads = max(1, pack_threads)
+        self.reuse_timeout_s = 600.0
 
     def submit(self, batched_videos, batched_masks) -> PendingInputs:
         slot = self.slots[self._next]
@@ -138,7 +148,11 @@ class InputStager:
             j.result()
 
     def _stage(self, slot: _Slot, batched_videos, batched_masks):
-        slot.released.wait()                 # the clip staged here before has been handed to its forward()
+        # the clip staged here before has been handed to its forward() (or discarded)
+        if not slot.released.wait(timeout=self.reuse_timeout_s):
+            raise RuntimeError(f"stage_inputs_async: the clip staged {len(self.slots)} submissions ago was neither passed to "
+                               f"forward(device_inputs=...) nor discarded within {self.reuse_timeout_s:.0f} s; its buffers "
+                               f"cannot be reused (call PendingInputs.discard() for clips that are dropped)")
         if slot.consumed is not None:
             slot.consumed.synchronize()      # ... and that forward() has finished on the GPU
             slot.consumed = None

@@ -63,3 +63,27 @@ def test_a_failed_staging_frees_its_buffer_set():
     ok = model.stage_inputs_async(kw["batched_videos"], kw["batched_masks"])
     out = model(**kw, device_inputs=ok)
     assert torch.equal(out[1][0].dense, model(**kw)[1][0].dense)
+
+
+def test_a_dropped_clip_is_discarded_or_reported():
+    cfg = config_by_name("tiny")
+    tok = HashTokenizer(cfg.vocab, cfg.bos_token_id, cfg.eos_token_id)
+    model = PredicateModel(None, None, "cuda:0", "tiny", tokenizer=tok, init_seed=4).eval()
+    b = make_clip_batch(61, n_videos=1, frames=2, objects=3, H=120, W=160, k_cate=4, k_unary=5, k_binary=3, min_box=12,
+                        max_box=100)
+    kw = b.forward_kwargs()
+    for _ in range(3):    # staged and dropped, more often than there are buffer sets
+        model.stage_inputs_async(kw["batched_videos"], kw["batched_masks"]).discard()
+    ok = model.stage_inputs_async(kw["batched_videos"], kw["batched_masks"])
+    assert torch.equal(model(**kw, device_inputs=ok)[1][0].dense, model(**kw)[1][0].dense)
+    # without discard() the third submission finds its buffer set still held and says so instead of waiting for ever
+    model._stager.reuse_timeout_s = 0.5
+    held = [model.stage_inputs_async(kw["batched_videos"], kw["batched_masks"]) for _ in range(2)]
+    for h in held:
+        h.result()
+    with pytest.raises(RuntimeError, match="discard"):
+        model.stage_inputs_async(kw["batched_videos"], kw["batched_masks"]).result()
+    for h in held:
+        h.discard()
+    ok = model.stage_inputs_async(kw["batched_videos"], kw["batched_masks"])
+    assert torch.equal(model(**kw, device_inputs=ok)[1][0].dense, model(**kw)[1][0].dense)
