@@ -12,9 +12,9 @@ There is no CPU fallback: without the HIP library or a GPU, construction fails.
 """
 from __future__ import annotations
 
-import os
-
 import functools
+import os
+import warnings
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -493,7 +493,6 @@ class PredicateModel(nn.Module):
             exact[groups] = True
             n_rescored += len(groups)
         for nm, margin, n in open_rows:
-            import warnings
             warnings.warn(f"pair selection of video {vid}: the candidates of {nm!r} at the top-{topk} boundary differ by "
                           f"{margin:.3e}, below what fp32 arithmetic resolves; the selected pairs may differ from another "
                           f"fp32 implementation's")
