@@ -28,6 +28,7 @@ struct AttnArgs {
     int q_tiles;  // ceil(T / 32)
     long long n_items;  // n_seq * heads
     int remap;    // workgroup order: blocks of one (sequence, head) on one XCD
+    int first_key_init;   // attn_shared_kernel: key 0 is the online softmax's initial state, the blocks cover keys 1 .. T - 1
 };
 
 __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_kernel(AttnArgs a) {
@@ -60,8 +61,32 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int g = 0; g < 16; g++) o0[g] = o1[g] = 0.f;
     float m_run = NEG_BIG, l_run = 0.f;
+    // key 0 as the initial state, the blocks over keys 1 .. T - 1: the same arithmetic, in the same order, as
+    // attn_shared_kernel's (the pooled rows of a long unmasked sequence equal the full kernel's rows bit for bit)
+    const int first = a.first_key_init;
+    const int Tk = T - first;
+    if (first) {
+        float dot = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const bf16x8 k0 = *(const bf16x8 *)(kbase + 16 * s + 8 * h);
+#pragma unroll
+            for (int j = 0; j < 8; j++) dot = __builtin_fmaf((float)qf[s][j], (float)k0[j], dot);
+        }
+        dot += __shfl_xor(dot, 32, 64);
+        m_run = dot * (0.125f * 1.4426950408889634f);
+        l_run = 1.0f;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const bf16x4 v0 = *(const bf16x4 *)(vbase + 32 * dt + 8 * gq + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; e++) (dt == 0 ? o0 : o1)[4 * gq + e] = (float)v0[e];
+            }
+    }
 
-    int n_end = T;
+    int n_end = Tk;
     if (a.causal) n_end = min(T, pooled ? m0 + 1 : m0 + 32);
     const int n_blocks = (n_end + 31) / 32;
     bf16_t *vt = vlds[wave];
@@ -69,7 +94,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_kernel(AttnArgs a) {
     for (int kb = 0; kb < n_blocks; kb++) {
         const int n0 = kb * 32;
         // K fragments (A operand): lane holds K[n0 + r][16 s + 8 h .. +7]
-        const int krow = min(n0 + r, T - 1);
+        const int krow = min(n0 + r, Tk - 1) + first;
         bf16x8 kf[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) kf[s] = *(const bf16x8 *)(kbase + (size_t)krow * ld + 16 * s + 8 * h);
@@ -77,7 +102,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_kernel(AttnArgs a) {
         bf16x8 vreg[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const int vr = min(n0 + 8 * t + (lane >> 3), T - 1);
+            const int vr = min(n0 + 8 * t + (lane >> 3), Tk - 1) + first;
             vreg[t] = *(const bf16x8 *)(vbase + (size_t)vr * ld + (lane & 7) * 8);
         }
         // The V tile is private to this wave and LDS operations of one wave execute in order, so
@@ -101,8 +126,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_kernel(AttnArgs a) {
 
         bf16x8 pb[2];
         float alpha;
-        if (n0 + 32 > T || kmask || (a.causal && n0 + 31 > m0))
-            alpha = online_softmax_step<true>(st, m_run, l_run, pb, n0, m, h, T, a.causal, kmask);
+        if (n0 + 32 > Tk || kmask || (a.causal && n0 + 31 > m0))
+            alpha = online_softmax_step<true>(st, m_run, l_run, pb, n0, m, h, Tk, a.causal, kmask);
         else
             alpha = online_softmax_step<false>(st, m_run, l_run, pb, n0, m, h, T, a.causal, kmask);
         if (__ballot(alpha != 1.0f)) {
@@ -196,17 +221,42 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_shared_kernel(AttnArgs
 #pragma unroll
     for (int g = 0; g < 16; g++) o0[g] = o1[g] = 0.f;
     float m_run = NEG_BIG, l_run = 0.f;
+    // Sequences of 32 n + 1 tokens (class token + a square of patches: 577, 257) would end in a key block with one key.
+    // There key 0 becomes the INITIAL STATE of the online softmax instead -- reference point = its score, weight 1, output =
+    // its value row -- and the blocks cover keys 1 .. T - 1, all of them full: one block and every masked step fewer.
+    const int first = a.first_key_init;
+    const int Tk = T - first;            // keys the blocks cover, starting at row `first`
+    if (first) {
+        float dot = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const bf16x8 k0 = *(const bf16x8 *)(kbase + 16 * s + 8 * h);
+#pragma unroll
+            for (int j = 0; j < 8; j++) dot = __builtin_fmaf((float)qf[s][j], (float)k0[j], dot);
+        }
+        dot += __shfl_xor(dot, 32, 64);
+        m_run = dot * (0.125f * 1.4426950408889634f);
+        l_run = 1.0f;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const bf16x4 v0 = *(const bf16x4 *)(vbase + 32 * dt + 8 * gq + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; e++) (dt == 0 ? o0 : o1)[4 * gq + e] = (float)v0[e];
+            }
+    }
 
     // keys the block needs: all of them, or up to its last query when causal
-    const int blk_end = a.causal ? min(T, (qg * ATT_WAVES + ATT_WAVES) * 32) : T;
+    const int blk_end = a.causal ? min(T, (qg * ATT_WAVES + ATT_WAVES) * 32) : Tk;
     const int n_blocks = (blk_end + 31) / 32;
-    const int my_end = a.causal ? min(T, m0 + 32) : T;
+    const int my_end = a.causal ? min(T, m0 + 32) : Tk;
     const int my_blocks = active ? (my_end + 31) / 32 : 0;
 
     // this thread's share of a K / V block: row tid >> 3 (32 rows), 16-byte chunk tid & 7
     const int lrow = threadIdx.x >> 3, lchunk = threadIdx.x & 7;
     auto fetch = [&](int kb, bf16x8 &kreg, bf16x8 &vreg) {
-        const int row = min(kb * 32 + lrow, T - 1);
+        const int row = min(kb * 32 + lrow, Tk - 1) + first;
         kreg = *(const bf16x8 *)(kbase + (size_t)row * ld + lchunk * 8);
         vreg = *(const bf16x8 *)(vbase + (size_t)row * ld + lchunk * 8);
     };
@@ -252,8 +302,8 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 3) void attn_shared_kernel(AttnArgs
         l_run += 1.0f;
 #else
         float alpha;
-        if (n0 + 32 > T || kmask || (a.causal && n0 + 31 > m0))
-            alpha = online_softmax_step<true>(st, m_run, l_run, pb, n0, m, h, T, a.causal, kmask);
+        if (n0 + 32 > Tk || kmask || (a.causal && n0 + 31 > m0))
+            alpha = online_softmax_step<true>(st, m_run, l_run, pb, n0, m, h, Tk, a.causal, kmask);
         else
             alpha = online_softmax_step<false>(st, m_run, l_run, pb, n0, m, h, T, a.causal, kmask);
         if (__ballot(alpha != 1.0f)) {
@@ -351,6 +401,12 @@ static int attention_launch(const void *qkv_dev, const int32_t *q_rows_dev, void
             remap = e ? atoi(e) : 1;
         }
         a.remap = remap;
+        static int first_key = -1;
+        if (first_key < 0) {
+            const char *e = getenv("SGCLIP_ATTN_FIRST_KEY");
+            first_key = e ? atoi(e) : 1;
+        }
+        a.first_key_init = first_key && T >= 128 && !causal && !key_mask_dev && T % 32 == 1;
     }
     if (!q_rows_dev && T >= 128) {
         const long long q_groups = (a.q_tiles + ATT_WAVES - 1) / ATT_WAVES;
