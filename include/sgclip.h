@@ -330,6 +330,12 @@ int sgclip_layernorm_bwd(const float *x_dev, int64_t x_stride, int rows, int d, 
  * workgroup, longer ones (up to ~6 000 tokens) a blocked kernel with recomputed row statistics. */
 int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, void *dqkv_dev, int n_seq, int T, int heads,
                          int causal, const int32_t *key_mask_dev, void *stream);
+/* The same, and dbias_dev f32 [3d] += the column sums of dqkv: the gradient of the fused q | k | v bias, which
+ * autograd forms as a sum over the rows of the projections' output gradient (nn.Linear under loss.backward(),
+ * scripts/train_sgclip.py:884).  For T <= 128 the sums leave the attention kernel itself (no pass over dqkv);
+ * the caller zeroes or pre-loads dbias_dev. */
+int sgclip_attention_bwd_bias(const void *qkv_dev, const void *dout_dev, void *dqkv_dev, float *dbias_dev, int n_seq, int T,
+                              int heads, int causal, const int32_t *key_mask_dev, void *stream);
 /* C[M][N] (+)= alpha op(A) op(B), fp32; op(A) = A [M,K] or, transA, A^T with A [K,M]; likewise B.
  * For the small fp32 tail (projection, similarity) where bf16 would cost accuracy. */
 int sgclip_matmul_f32(const float *A_dev, int64_t lda, int transA, const float *B_dev, int64_t ldb, int transB,

@@ -103,6 +103,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sgclip_attention_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p]),
+    "sgclip_attention_bwd_bias": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p]),
     "sgclip_matmul_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                     C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "sgclip_dot_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -403,7 +403,8 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <int TP>
 __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
                                                                  bf16_t *__restrict__ dqkv, int T, int heads, int causal,
-                                                                 const int32_t *__restrict__ key_mask) {
+                                                                 const int32_t *__restrict__ key_mask,
+                                                                 float *__restrict__ dbias, int colsum_off) {
     constexpr int LDR = 72, LDT = TP + 8, NT = TP / 16, RT = (NT + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t *Qt = (bf16_t *)smem, *Kt = Qt + 64 * LDT, *dOt = Kt + 64 * LDT;
@@ -542,6 +543,14 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t *_
 
     // ---- phase B
     bf16_t *obase = dqkv + (size_t)seq * T * ld + head * 64;
+    // dbias: the column sums of this workgroup's dqkv block (the gradient of the q, k, v biases) ride along: per lane the
+    // rounded values of its column over its rows, then the lane quarters, the four waves through LDS, and one
+    // 64-float contiguous atomic per matrix
+    float cs[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) cs[q][c] = 0.f;
 #pragma unroll
     for (int r2 = 0; r2 < RT; r2++) {
         const int rt = wave + 4 * r2;
@@ -575,24 +584,48 @@ __global__ __launch_bounds__(256) void attention_bwd_mfma_kernel(const bf16_t *_
             bf16_t *o = obase + (size_t)t * ld + frow;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                o[c * 16] = (bf16_t)aQ[c][e];
-                o[d + c * 16] = (bf16_t)aK[c][e];
-                o[2 * d + c * 16] = (bf16_t)aV[c][e];
+                const bf16_t gq = (bf16_t)aQ[c][e], gk = (bf16_t)aK[c][e], gv = (bf16_t)aV[c][e];
+                o[c * 16] = gq;
+                o[d + c * 16] = gk;
+                o[2 * d + c * 16] = gv;
+                cs[0][c] += (float)gq;
+                cs[1][c] += (float)gk;
+                cs[2][c] += (float)gv;
             }
+        }
+    }
+    if (dbias) {
+        float *part = (float *)(smem + colsum_off);   // [4 waves][3][64]
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float v = cs[q][c];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (fq == 0) part[(wave * 3 + q) * 64 + c * 16 + frow] = v;
+            }
+        __syncthreads();
+        if (threadIdx.x < 192) {
+            const int q = threadIdx.x >> 6, col = threadIdx.x & 63;
+            const float v = part[q * 64 + col] + part[(3 + q) * 64 + col] + part[(6 + q) * 64 + col] + part[(9 + q) * 64 + col];
+            atomicAdd(dbias + (size_t)q * d + head * 64 + col, v);
         }
     }
 }
 
 template <int TP>
 static void attention_bwd_mfma_launch(const bf16_t *qkv, const bf16_t *dout, bf16_t *dqkv, int n_seq, int T, int heads,
-                                      int causal, const int32_t *km, hipStream_t stream) {
+                                      int causal, const int32_t *km, float *dbias, hipStream_t stream) {
     constexpr int LDT = TP + 8;
     constexpr size_t phase_a = (size_t)4 * TP * 72 * 2, phase_b = (size_t)3 * TP * LDT * 2;
-    constexpr size_t lds = (size_t)3 * 64 * LDT * 2 + (phase_a > phase_b ? phase_a : phase_b);
+    constexpr size_t body = (size_t)3 * 64 * LDT * 2 + (phase_a > phase_b ? phase_a : phase_b);
+    constexpr size_t lds = body + 4 * 3 * 64 * sizeof(float);   // + the waves' column sums
     static_assert(lds <= 160 * 1024, "attention backward tile exceeds the LDS");
+    static_assert(body % 16 == 0, "column sums start aligned");
     if (!lds_attr((const void *)attention_bwd_mfma_kernel<TP>, (int)lds)) return;   // the error text is set; launch_check reports it
     hipLaunchKernelGGL(attention_bwd_mfma_kernel<TP>, dim3((unsigned)(n_seq * heads)), dim3(256), lds, stream, qkv, dout, dqkv,
-                       T, heads, causal, km);
+                       T, heads, causal, km, dbias, (int)body);
 }
 
 // ---------------------------------------------------------------------------
@@ -1099,10 +1132,33 @@ extern "C" int sgclip_layernorm_bwd(const float *x_dev, int64_t x_stride, int ro
     return launch_check("sgclip_layernorm_bwd");
 }
 
+static int attention_bwd_impl(const void *qkv_dev, const void *dout_dev, void *dqkv_dev, int n_seq, int T, int heads,
+                              int causal, const int32_t *key_mask_dev, float *dbias_dev, void *stream);
+
 extern "C" int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, void *dqkv_dev, int n_seq, int T, int heads,
                                     int causal, const int32_t *key_mask_dev, void *stream) {
+    return attention_bwd_impl(qkv_dev, dout_dev, dqkv_dev, n_seq, T, heads, causal, key_mask_dev, nullptr, stream);
+}
+
+extern "C" int sgclip_attention_bwd_bias(const void *qkv_dev, const void *dout_dev, void *dqkv_dev, float *dbias_dev, int n_seq,
+                                         int T, int heads, int causal, const int32_t *key_mask_dev, void *stream) {
+    if (!dbias_dev) {
+        set_error("sgclip_attention_bwd_bias: dbias_dev is null");
+        return SGCLIP_EINVAL;
+    }
+    return attention_bwd_impl(qkv_dev, dout_dev, dqkv_dev, n_seq, T, heads, causal, key_mask_dev, dbias_dev, stream);
+}
+
+// dbias_dev (or null): f32 [3d] += column sums of dqkv.  The matrix-core kernel of short sequences adds them itself; behind
+// the other kernels the column-sum kernel runs over their result.
+static int attention_bwd_impl(const void *qkv_dev, const void *dout_dev, void *dqkv_dev, int n_seq, int T, int heads,
+                              int causal, const int32_t *key_mask_dev, float *dbias_dev, void *stream) {
     if (n_seq == 0) return SGCLIP_OK;
     BWD_ARGS_OK(qkv_dev && dout_dev && dqkv_dev && n_seq > 0 && T > 0 && heads > 0, "sgclip_attention_bwd");
+    auto then_colsum = [&](int rc) {
+        if (rc != SGCLIP_OK || !dbias_dev) return rc;
+        return sgclip_colsum(dqkv_dev, SGCLIP_DTYPE_BF16, (int64_t)3 * heads * 64, n_seq * T, 3 * heads * 64, dbias_dev, stream);
+    };
     if (T > 128) {
         // long sequences: blocked kernel with recomputed statistics
         const int TP = (T + LB - 1) / LB * LB;
@@ -1115,7 +1171,7 @@ extern "C" int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, v
         if (!lds_attr((const void *)attention_bwd_long_kernel, 160 * 1024)) return SGCLIP_ELAUNCH;
         hipLaunchKernelGGL(attention_bwd_long_kernel, dim3((unsigned)(n_seq * heads)), dim3(256), lds, (hipStream_t)stream,
                            (const bf16_t *)qkv_dev, (const bf16_t *)dout_dev, (bf16_t *)dqkv_dev, T, heads, causal, key_mask_dev);
-        return launch_check("sgclip_attention_bwd");
+        return then_colsum(launch_check("sgclip_attention_bwd"));
     }
     static int use_valu = -1;   // SGCLIP_ATTN_BWD_VALU=1: the plain VALU kernel (cross-check)
     if (use_valu < 0) {
@@ -1127,20 +1183,20 @@ extern "C" int sgclip_attention_bwd(const void *qkv_dev, const void *dout_dev, v
         bf16_t *g = (bf16_t *)dqkv_dev;
         hipStream_t hs = (hipStream_t)stream;
         if (T <= 32)
-            attention_bwd_mfma_launch<32>(q, o, g, n_seq, T, heads, causal, key_mask_dev, hs);
+            attention_bwd_mfma_launch<32>(q, o, g, n_seq, T, heads, causal, key_mask_dev, dbias_dev, hs);
         else if (T <= 64)
-            attention_bwd_mfma_launch<64>(q, o, g, n_seq, T, heads, causal, key_mask_dev, hs);
+            attention_bwd_mfma_launch<64>(q, o, g, n_seq, T, heads, causal, key_mask_dev, dbias_dev, hs);
         else if (T <= 96)
-            attention_bwd_mfma_launch<96>(q, o, g, n_seq, T, heads, causal, key_mask_dev, hs);
+            attention_bwd_mfma_launch<96>(q, o, g, n_seq, T, heads, causal, key_mask_dev, dbias_dev, hs);
         else
-            attention_bwd_mfma_launch<128>(q, o, g, n_seq, T, heads, causal, key_mask_dev, hs);
+            attention_bwd_mfma_launch<128>(q, o, g, n_seq, T, heads, causal, key_mask_dev, dbias_dev, hs);
         return launch_check("sgclip_attention_bwd");
     }
     const size_t lds = (size_t)4 * T * 64 * sizeof(bf16_t) + (size_t)T * T * sizeof(float);
     if (!lds_attr((const void *)attention_bwd_kernel, 160 * 1024)) return SGCLIP_ELAUNCH;
     hipLaunchKernelGGL(attention_bwd_kernel, dim3((unsigned)(n_seq * heads)), dim3(256), lds, (hipStream_t)stream,
                        (const bf16_t *)qkv_dev, (const bf16_t *)dout_dev, (bf16_t *)dqkv_dev, T, heads, causal, key_mask_dev);
-    return launch_check("sgclip_attention_bwd");
+    return then_colsum(launch_check("sgclip_attention_bwd"));
 }
 
 extern "C" int sgclip_matmul_f32(const float *A_dev, int64_t lda, int transA, const float *B_dev, int64_t ldb, int transB,

@@ -118,12 +118,18 @@ def layernorm_bwd(x: torch.Tensor, w: torch.Tensor, eps: float, dy: torch.Tensor
 
 
 def attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, n_seq: int, T: int, heads: int, causal: bool,
-                  key_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  key_mask: Optional[torch.Tensor] = None, dbias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dqkv; with dbias (f32 [3d]) the column sums of dqkv are ADDED to it (the q | k | v bias gradient)."""
     assert qkv.dtype == BF16 and dout.dtype == BF16 and qkv.is_contiguous() and dout.is_contiguous()
     assert qkv.shape == (n_seq * T, 3 * heads * 64) and dout.shape == (n_seq * T, heads * 64)
     dqkv = torch.empty_like(qkv)
-    _lib.check(_lib.load().sgclip_attention_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), n_seq, T, heads,
-                                                1 if causal else 0, _ptr(key_mask), _stream(qkv)))
+    if dbias is None:
+        _lib.check(_lib.load().sgclip_attention_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), n_seq, T, heads,
+                                                    1 if causal else 0, _ptr(key_mask), _stream(qkv)))
+    else:
+        assert dbias.dtype == F32 and dbias.is_contiguous() and dbias.numel() == 3 * heads * 64
+        _lib.check(_lib.load().sgclip_attention_bwd_bias(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), dbias.data_ptr(), n_seq,
+                                                         T, heads, 1 if causal else 0, _ptr(key_mask), _stream(qkv)))
     return dqkv
 
 

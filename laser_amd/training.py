@@ -156,12 +156,11 @@ class TrainTower:
         dxb = G.cast_bf16_colsum(dx, sink.get(f"{b}.self_attn.out_proj.bias"))
         G.linear_wgrad(dxb, a, sink.get(f"{b}.self_attn.out_proj.weight"))
         da = G.linear_dgrad(dxb, w[f"{i}.o_t"], zb)
-        dqkv = G.attention_bwd(qkv, da, n_seq, T, self.heads, causal, km)
+        wq, bq = sink.qkv(b, d)
+        dqkv = G.attention_bwd(qkv, da, n_seq, T, self.heads, causal, km, dbias=bq)   # the bias gradient rides along
         if h1 is None:
             h1 = ops.layernorm(x, self._p(f"{b}.layer_norm1.weight"), self._p(f"{b}.layer_norm1.bias"), self.eps)
-        wq, bq = sink.qkv(b, d)
         G.linear_wgrad(dqkv, h1, wq)
-        G.colsum(dqkv, bq)
         dh1 = G.linear_dgrad(dqkv, w[f"{i}.qkv_t"], zb)
         G.layernorm_bwd(x, self._p(f"{b}.layer_norm1.weight"), self.eps, dh1, sink.get(f"{b}.layer_norm1.weight"),
                         sink.get(f"{b}.layer_norm1.bias"), dx=dx, accumulate=True)

@@ -222,6 +222,13 @@ def test_attention_bwd(dev, n_seq, T, heads, causal, masked):
     err = (dqkv.float() - ref_in.grad).abs().max().item()
     assert err <= 2e-2 * max(1.0, ref_in.grad.abs().max().item()), err
     assert _rel(dqkv, ref_in.grad) <= 1e-2
+    # with the bias gradient riding along: the same dqkv bit for bit, and its column sums ADDED to what dbias held
+    dbias = torch.full((3 * d,), 0.5, dtype=torch.float32, device=dev)
+    dqkv2 = G.attention_bwd(qkv, dout, n_seq, T, heads, causal, km, dbias=dbias)
+    torch.cuda.synchronize()
+    assert torch.equal(dqkv2, dqkv)
+    want = 0.5 + dqkv.double().sum(dim=0)
+    assert (dbias.double() - want).abs().max().item() <= 1e-4 * max(1.0, want.abs().max().item())
 
 
 @pytest.mark.parametrize("M,N,K,tA,tB", [(5, 7, 3, False, False), (130, 70, 33, True, False), (64, 512, 768, False, True),
