@@ -200,7 +200,10 @@ def test_attention_pooled_equals_the_full_kernel_rows(dev, n_seq, T, heads, caus
 
 
 @pytest.mark.parametrize("n_seq,T,heads", [(5, 50, 12), (23, 50, 4), (1, 50, 2), (7, 37, 3), (4, 64, 2), (3, 100, 2),
-                                           (6, 128, 2), (300, 50, 12)])
+                                           (6, 128, 2), (300, 50, 12),
+                                           # the three-slot kernel (d >= 256) at its smallest depth, at ViT-L width with the
+                                           # heads in four groups over several row tiles, and with a ragged last tile
+                                           (23, 50, 16), (2, 128, 8), (11, 50, 5), (1, 3, 4)])
 def test_fused_qkv_attention_equals_the_separate_kernels(dev, n_seq, T, heads):
     """sgclip_qkv_attention against sgclip_gemm_bf16(BIAS_BF16) + sgclip_attention and against fp32 torch."""
     d = heads * 64
