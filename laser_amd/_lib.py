@@ -32,7 +32,7 @@ class CropEntry(C.Structure):
     _fields_ = [("frame_off", C.c_int64), ("mask_a_off", C.c_int64), ("mask_b_off", C.c_int64),
                 ("frame_w", C.c_int32), ("frame_h", C.c_int32),
                 ("x1", C.c_int32), ("y1", C.c_int32), ("x2", C.c_int32), ("y2", C.c_int32),
-                ("mode", C.c_int32), ("reserved", C.c_int32)]
+                ("mode", C.c_int32), ("order", C.c_int32)]
 
 
 class MaskEntry(C.Structure):

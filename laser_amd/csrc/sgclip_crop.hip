@@ -280,8 +280,10 @@ __global__ __launch_bounds__(NT, 4) void crop_kernel(CropArgs a) {
     const int grp = tid / COLS, gcol = tid % COLS;  // grp is wave-uniform
     const int bpw = a.bands_per_wg;
     const int wg_per_crop = a.nbands / bpw;
-    const int crop_i = blockIdx.x / wg_per_crop;
-    const int band0 = (blockIdx.x - crop_i * wg_per_crop) * bpw;
+    const int slot = blockIdx.x / wg_per_crop;
+    const int band0 = (blockIdx.x - slot * wg_per_crop) * bpw;
+    const int ord = a.crops[slot].order;          // 1 + the crop this group of workgroups takes, or 0: its own slot
+    const int crop_i = ord > 0 ? ord - 1 : slot;
     const int vrows = bpw * BR;
     const sgclip_crop_t c = a.crops[crop_i];
     const int S = a.S;
@@ -679,8 +681,10 @@ __global__ __launch_bounds__(NTM, (NBW <= 2 && KB == 1) ? 4 : 2) void crop_mfma_
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bpw = a.bands_per_wg;
     const int wg_per_crop = a.nbands / bpw;
-    const int crop_i = blockIdx.x / wg_per_crop;
-    const int band0 = (blockIdx.x - crop_i * wg_per_crop) * bpw;
+    const int slot = blockIdx.x / wg_per_crop;
+    const int band0 = (blockIdx.x - slot * wg_per_crop) * bpw;
+    const int ord = a.crops[slot].order;          // 1 + the crop this group of workgroups takes, or 0: its own slot
+    const int crop_i = ord > 0 ? ord - 1 : slot;
     const int vrows = bpw * BR;
     const sgclip_crop_t c = a.crops[crop_i];
     const int S = a.S;
@@ -1102,6 +1106,23 @@ extern "C" int sgclip_crop_preprocess(const uint8_t *frames_dev, size_t frames_b
     int ksx[5], ksy[5], wnc[5], members[5];
     int mksx[2], mksy[2], mwnc[2], mmembers[2], mwin[2][2];   // mwin[class][windows - 1]: members by window count
     double algo_bytes = 0;  // per crop: 3hw frame + m*hw mask + out
+    {   // the order hints: all zero, or a permutation of 1 .. n
+        int nonzero = 0;
+        for (int i = 0; i < n_crops; i++) nonzero += crops[i].order != 0;
+        if (nonzero) {
+            std::vector<unsigned char> seen((size_t)n_crops, 0);
+            bool ok = nonzero == n_crops;
+            for (int i = 0; ok && i < n_crops; i++) {
+                const int o = crops[i].order;
+                ok = o >= 1 && o <= n_crops && !seen[o - 1];
+                if (ok) seen[o - 1] = 1;
+            }
+            if (!ok) {
+                set_error("sgclip_crop_preprocess: the order fields must be all zero or a permutation of 1 .. %d", n_crops);
+                return SGCLIP_EINVAL;
+            }
+        }
+    }
     for (;;) {
         bool too_big = false;
         for (int k = 0; k < 5; k++) ksx[k] = ksy[k] = wnc[k] = 1, members[k] = 0;

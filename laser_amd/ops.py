@@ -82,6 +82,14 @@ def crop_preprocess(frames: torch.Tensor, masks: Optional[torch.Tensor], entries
             out = torch.zeros((n * P, kpad), dtype=tdt, device=dev)
         else:
             out = torch.empty((n, 3, S, S), dtype=tdt, device=dev)
+    if entries_dev is None and isinstance(entries, np.ndarray) and entries.dtype.names and "order" in entries.dtype.names:
+        # scheduling hint: largest boxes first, so that the launch does not end on a few big crops (their
+        # workgroups take ten times as long as a small crop's); few crops: table order
+        if n >= CROP_ORDER_MIN and CROP_ORDER:
+            area = (entries["x2"] - entries["x1"]).astype(np.int64) * (entries["y2"] - entries["y1"])
+            entries["order"] = np.argsort(-area, kind="stable").astype(np.int32) + 1
+        else:
+            entries["order"] = 0
     pinned = None
     if entries_dev is None and n and PINNED_TABLES:
         # the table goes up from pinned memory with an asynchronous copy queued on this stream: a copy from pageable
@@ -131,6 +139,8 @@ def _host_table_ptr(entries) -> int:
 
 
 PINNED_TABLES = os.environ.get("SGCLIP_PINNED_TABLES", "1") != "0"   # 0: small tables go up from pageable memory (comparison)
+CROP_ORDER = os.environ.get("SGCLIP_CROP_ORDER", "1") != "0"   # crop tables get the largest-first scheduling hint
+CROP_ORDER_MIN = 256                                           # ... from this many crops on
 PAD = 16  # slack bytes appended to frame / mask buffers (the kernel copies rows in 16-byte pieces)
 
 

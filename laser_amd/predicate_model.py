@@ -29,7 +29,7 @@ from .weights import TOWER_PREFIXES, random_state_dict
 
 CROP_DTYPE = np.dtype([("frame_off", "<i8"), ("mask_a_off", "<i8"), ("mask_b_off", "<i8"), ("frame_w", "<i4"),
                        ("frame_h", "<i4"), ("x1", "<i4"), ("y1", "<i4"), ("x2", "<i4"), ("y2", "<i4"), ("mode", "<i4"),
-                       ("reserved", "<i4")])
+                       ("order", "<i4")])
 assert CROP_DTYPE.itemsize == 56
 
 

@@ -417,6 +417,54 @@ def test_crop_errors(dev):
         ops.crop_preprocess(frames_t, None, _entries([(0, -1, -1, 100, 100, 10, 10, 50, 20, _lib.CROP_OBJECT)]), 64)
 
 
+def test_crop_order_hint_changes_the_schedule_not_the_result(dev):
+    """The order field moves crops between workgroups (largest first); every crop's output stays where its index says,
+    bit for bit.  Anything but all zeros or a permutation of 1 .. n is refused."""
+    from laser_amd.predicate_model import CROP_DTYPE
+    rng = np.random.default_rng(5)
+    H, W, n = 360, 640, 300
+    frames = rng.integers(0, 256, size=(2, H, W, 3), dtype=np.uint8)
+    masks = rng.random((3, H, W)) < 0.5
+    frames_t = torch.from_numpy(ops.pad_bytes(frames)).to(dev)
+    masks_t = torch.from_numpy(ops.pad_bytes(masks.astype(np.uint8))).to(dev)
+    rows = []
+    for i in range(n):
+        w, h = int(np.exp(rng.uniform(np.log(8), np.log(W)))), int(np.exp(rng.uniform(np.log(8), np.log(H))))
+        x1, y1 = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+        rows.append(((i % 2) * H * W * 3, (i % 3) * H * W, ((i + 1) % 3) * H * W, W, H, x1, y1, x1 + w, y1 + h,
+                     (_lib.CROP_OBJECT, _lib.CROP_PAIR, _lib.CROP_PLAIN)[i % 3], 0))
+    table = np.array(rows, dtype=CROP_DTYPE)
+    kw = dict(layout=_lib.LAYOUT_PATCHES, patch=32, out_dtype=_lib.DTYPE_BF16)
+    old = ops.CROP_ORDER
+    try:
+        ops.CROP_ORDER = False
+        plain = ops.crop_preprocess(frames_t, masks_t, table.copy(), 224, **kw)
+        ops.CROP_ORDER = True
+        hinted_table = table.copy()
+        hinted = ops.crop_preprocess(frames_t, masks_t, hinted_table, 224, **kw)
+    finally:
+        ops.CROP_ORDER = old
+    torch.cuda.synchronize()
+    assert sorted(hinted_table["order"].tolist()) == list(range(1, n + 1))
+    first = int(hinted_table["order"][0]) - 1
+    area = (table["x2"] - table["x1"]).astype(np.int64) * (table["y2"] - table["y1"])
+    assert area[first] == area.max()
+    assert torch.equal(plain, hinted)
+    # a reversed and a random permutation given by the caller (the table uploaded as it is)
+    for perm in (np.arange(n)[::-1], rng.permutation(n)):
+        t = table.copy()
+        t["order"] = perm.astype(np.int32) + 1
+        tdev = torch.from_numpy(t.view(np.uint8).reshape(-1).copy()).to(dev)
+        got = ops.crop_preprocess(frames_t, masks_t, t, 224, entries_dev=tdev, entries_dev_ready=True, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(plain, got)
+    bad = table.copy()
+    bad["order"] = 1                      # not a permutation
+    tdev = torch.from_numpy(bad.view(np.uint8).reshape(-1).copy()).to(dev)
+    with pytest.raises(_lib.SgclipError, match="permutation"):
+        ops.crop_preprocess(frames_t, masks_t, bad, 224, entries_dev=tdev, entries_dev_ready=True, **kw)
+
+
 def test_crop_sweep_at_720p_vs_oracle(dev):
     """Boxes drawn log-uniformly in size on 1280 x 720 frames (the benchmark's distribution) plus thin, tiny and
     frame-sized ones, all crop modes, S = 224: every variant of the matrix-core crop kernel and the vector kernel it
